@@ -1,0 +1,162 @@
+/*
+ * rt.h -- C ABI of librtmi.so, the MI355X (gfx950) implementation of the
+ * path-tracing hot path of Zelmoghazy/RayTracer.
+ *
+ * The reference has no render(camera, world, framebuffer, spp, max_depth)
+ * function: its frame loop calls render_all_parallel() (Main.c:990-1082),
+ * which reads the global `gc` (Main.c:97-158).  The entry points below are the
+ * boundary carved out at Main.c:1002-1054 (the 64x64-tile / thread dispatch
+ * around render_tile, Main.c:959-988): everything before it (framebuffer
+ * allocation, Main.c:998) and after it (text overlay, capture, present_frame,
+ * Main.c:1056-1081, 1181-1185) keeps running on the caller-owned RGBA8 buffer.
+ *
+ * Plain C structs and pointers only.  Every function returns 0 on success or a
+ * negative rt_status; nothing throws or exits across the boundary; the text of
+ * the last error of the calling process is available from rt_last_error().
+ * Calls are blocking and not re-entrant (the reference calls its renderer from
+ * the one GLFW thread, Main.c:1440-1443).
+ */
+#ifndef RT_H_
+#define RT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_vec3 { float x, y, z; } rt_vec3;          /* vec3f_t, include/util.h:245-250 */
+
+/* enum material_type, Main.c:45-51 */
+enum { RT_MAT_LAMBERTIAN = 0, RT_MAT_METAL = 1, RT_MAT_DIELECTRIC = 2 };
+
+/* One scene object: byte-for-byte the reference's sphere_t (Main.c:74-79) with its
+ * embedded material_t (Main.c:53-59); 40 bytes.  The library flattens the array
+ * into structure-of-arrays form on upload. */
+typedef struct rt_sphere {
+    rt_vec3 center;
+    float   radius;
+    int32_t mat_type;
+    rt_vec3 albedo;
+    float   fuzz;
+    float   refraction_index;
+} rt_sphere;
+
+/* What the path reads of the camera: gc.camera.pos, gc.pixel00_loc,
+ * gc.pixel_delta_u/v, gc.camera.defocus_disk_u/v, gc.camera.defocus_angle
+ * (Main.c:107-109, 26, 37, 40-41; consumed by get_ray, Main.c:776-803). */
+typedef struct rt_camera {
+    rt_vec3 pos;
+    rt_vec3 pixel00_loc;
+    rt_vec3 pixel_delta_u;
+    rt_vec3 pixel_delta_v;
+    rt_vec3 defocus_disk_u;
+    rt_vec3 defocus_disk_v;
+    float   defocus_angle;
+} rt_camera;
+
+/* Inputs of update_camera_view (Main.c:839-904); defaults of init_camera (Main.c:915-922). */
+typedef struct rt_camera_params {
+    rt_vec3 pos, target, up;
+    float   vfov;            /* degrees */
+    float   defocus_angle;   /* degrees */
+    float   focus_dist;
+} rt_camera_params;
+
+enum {
+    RT_MODE_MC      = 0,  /* Monte-Carlo: counter-based RNG keyed (seed, pixel, sample) */
+    RT_MODE_CONST_U = 1   /* deterministic: every random draw returns 0.5, i.e. the
+                             reference with fast_rand() == 16384: centre sample, ray
+                             origin = camera.pos, scatter along the normal */
+};
+
+typedef struct rt_stats {
+    uint64_t samples;        /* pixel samples traced by this call                  */
+    uint64_t rays;           /* calls of hit() (Main.c:688), i.e. rays cast         */
+    uint64_t sphere_tests;   /* rays * number of spheres (hit_sphere calls)         */
+    double   kernel_ms;      /* device time of the path-tracing kernel(s), HIP events */
+    double   total_ms;       /* wall time of the call                               */
+} rt_stats;
+
+typedef struct rt_opts {
+    int32_t  mode;           /* RT_MODE_*                                            */
+    int32_t  strict_fp;      /* 1: no FMA contraction, IEEE sqrt/div: results are bit-
+                                identical to the CPU mirror; 0: fast kernel (FMA,
+                                normalised directions), statistically equivalent     */
+    uint32_t seed;           /* RNG seed (MC mode)                                   */
+    uint32_t sample_base;    /* index of the first sample (progressive frames pass
+                                frame*spp so that frames draw disjoint streams)      */
+    int32_t  chunk_spp;      /* samples per work unit; a pixel's sum is the in-order
+                                sum of its chunks' in-order partial sums.  0 = spp   */
+    int32_t  tile_rows;      /* multi-GPU row-tile height (0 = 16)                   */
+    int32_t  part_index;     /* this call renders row tiles t with                   */
+    int32_t  part_count;     /*   t % part_count == part_index  (0 or 1 = all rows)  */
+    int32_t *hit_index_out;  /* optional, width*height: index of the object hit by
+                                the primary ray of the last sample, -1 = sky         */
+    float   *accum_out;      /* optional, width*height*3: linear mean colour (before
+                                gamma and quantisation)                              */
+    rt_stats *stats;         /* optional                                             */
+} rt_opts;
+
+enum rt_status {
+    RT_OK = 0,
+    RT_ERR_ARG = -1,         /* bad argument                                          */
+    RT_ERR_STATE = -2,       /* rt_init / rt_set_world not called                     */
+    RT_ERR_DEVICE = -3,      /* HIP error or no gfx950 device                         */
+    RT_ERR_NOMEM = -4
+};
+
+/* Selects HIP device `device` for this process and creates the stream, events and
+ * device buffers the path needs.  No reference counterpart (the reference spawns
+ * OS threads per tile, Main.c:1002-1045). */
+int rt_init(int device);
+
+/* Replaces gc.scene_objects (Main.c:116, filled by init_scene, Main.c:1212-1318).
+ * `spheres` is copied; only RT_MAT_LAMBERTIAN/METAL/DIELECTRIC are accepted (the
+ * reference's Emissive case leaves the scattered ray uninitialised, Main.c:613-619). */
+int rt_set_world(const rt_sphere *spheres, size_t count);
+
+/* Replaces the tile/thread dispatch of render_all_parallel (Main.c:1002-1054) and
+ * the per-pixel work of render_tile (Main.c:959-988): get_ray, ray_color, hit,
+ * hit_sphere, ray_scatter, 1/spp scale, linear_to_gamma, to_color4, set_pixel.
+ * `rgba` is caller-owned HOST memory, width*height*4 bytes, row 0 = top, alpha 255
+ * (color4_t, include/util.h:227-233; BUF_AT, include/base_graphics.h:13).  With
+ * opts->part_count > 1 only the owned rows are written, at their place in the
+ * full image.  `opts` may be NULL (MC, fast kernel, seed 0, all rows). */
+int rt_render(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height,
+              int spp, int max_depth, const rt_opts *opts);
+
+/* Same as rt_render, but `rgba_dev` (and opts->hit_index_out / accum_out) are DEVICE
+ * pointers on the device given to rt_init, so that a multi-GPU caller can hand the
+ * rows to RCCL without a host round trip.  With opts->part_count > 1 the buffers are
+ * COMPACT: they hold only the owned rows, in image order, rt_part_rows() of them. */
+int rt_render_device(const rt_camera *cam, uint8_t *rgba_dev, uint32_t width, uint32_t height,
+                     int spp, int max_depth, const rt_opts *opts);
+
+/* Number of image rows owned by part `part_index` of `part_count` (row tiles of
+ * `tile_rows` rows dealt round-robin).  Pure host arithmetic. */
+uint32_t rt_part_rows(uint32_t height, int tile_rows, int part_index, int part_count);
+
+/* Image row of the k-th owned row of a part (inverse of the compaction above). */
+uint32_t rt_part_row_at(uint32_t k, int tile_rows, int part_index, int part_count);
+
+/* update_camera_view (Main.c:839-904) restated on the host, quirks included
+ * (tan_f32 takes turns but is fed radians, include/util.h:134,142).  A host that
+ * keeps the reference's own update_camera_view does not need this. */
+int rt_camera_setup(const rt_camera_params *p, uint32_t width, uint32_t height, rt_camera *out);
+
+/* init_camera's defaults (Main.c:915-922) and its height rule (Main.c:908). */
+void rt_camera_defaults(rt_camera_params *p);
+uint32_t rt_height_for(uint32_t width, float aspect_ratio);
+
+/* Frees everything rt_init / rt_set_world created. */
+void rt_shutdown(void);
+
+/* Text of the last error reported to this process ("" if none). */
+const char *rt_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_H_ */

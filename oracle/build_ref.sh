@@ -1,0 +1,51 @@
+#!/usr/bin/env bash
+# Builds the COMPILED REFERENCE used as ground truth (test infrastructure only).
+#
+# Sources are read where they lie under /root/reference and streamed through the
+# compiler; nothing is copied into this repository.  Outputs go to oracle/_ref/
+# (git-ignored).  Three build-time edits are applied on the fly, none of which
+# touches the arithmetic of the path:
+#   1. src/util.c:29 defines fast_srand(u32) while include/util.h:276 declares
+#      fast_srand(int) -> gcc rejects the mismatch; the definition is made (int).
+#   2. src/util.c:35 fast_rand is renamed ref_lcg_fast_rand so the driver can
+#      switch to the constant-u deterministic mode (fast_rand() == 16384).
+#   3. Main.c:1226 '#if 0' (random-sphere block) becomes '#if 1' for the
+#      final-scene binary ref_harness_sf; ref_harness_s3 keeps it off.
+# The window/OpenGL code in Main.c is never reached from the driver's main();
+# it is dropped by --gc-sections together with its references to GLFW/GLEW,
+# which are not installed here, so no stand-in library is needed.
+set -euo pipefail
+R=${REFERENCE_DIR:-/root/reference}
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/_ref"
+if [ ! -f "$R/Main.c" ]; then
+    echo "build_ref: $R/Main.c not present; nothing to do" >&2
+    exit 0
+fi
+mkdir -p "$OUT"
+CF=(-std=gnu2x -O2 -ffp-contract=off -DGLEW_NO_GLU '-D__declspec(x)=__thread'
+    -include unistd.h -include limits.h -I"$R" -I"$R/include" -I"$R/src"
+    -I"$R/external/include" -ffunction-sections -fdata-sections -w)
+
+sed -n '1226p' "$R/Main.c" | grep -q '#if 0' || { echo "build_ref: Main.c:1226 is not '#if 0'" >&2; exit 1; }
+grep -q '^void fast_srand(u32 seed)' "$R/src/util.c" || { echo "build_ref: util.c fast_srand anchor missing" >&2; exit 1; }
+grep -q '^int fast_rand(void)' "$R/src/util.c" || { echo "build_ref: util.c fast_rand anchor missing" >&2; exit 1; }
+
+sed -e 's/^void fast_srand(u32 seed)/void fast_srand(int seed)/' \
+    -e 's/^int fast_rand(void)/int ref_lcg_fast_rand(void)/' "$R/src/util.c" \
+    | gcc "${CF[@]}" -x c - -c -o "$OUT/util.o"
+gcc "${CF[@]}" -fgnu89-inline -c "$R/src/base_graphics.c" -o "$OUT/base_graphics.o"
+gcc "${CF[@]}" -c "$R/src/arena.c" -o "$OUT/arena.o"
+
+for variant in s3:0 sf:1; do
+    name=${variant%%:*}; on=${variant##*:}
+    { echo '#define main ref_main'
+      sed "1226s/#if 0/#if $on/" "$R/Main.c"
+      echo '#undef main'
+      cat "$HERE/ref_harness.c"; } \
+      | gcc "${CF[@]}" -x c - -c -o "$OUT/harness_$name.o"
+    gcc -Wl,--gc-sections "$OUT/harness_$name.o" "$OUT/util.o" "$OUT/base_graphics.o" "$OUT/arena.o" \
+        -o "$OUT/ref_harness_$name" -lm -lpthread
+done
+rm -f "$OUT"/*.o
+echo "build_ref: built $OUT/ref_harness_s3 $OUT/ref_harness_sf"
