@@ -1,0 +1,194 @@
+"""raytracer_amd -- host-side Python mirror of the C ABI in include/rt.h.
+
+The compute path is librtmi.so (hand-written HIP for gfx950).  This module only loads it
+with ctypes and marshals numpy arrays / raw device pointers; there is no CPU fallback:
+if the library is missing or no gfx950 device is present, calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librtmi.so")
+CSRC = os.path.join(HERE, "csrc")
+
+MODE_MC, MODE_CONST_U = 0, 1
+MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
+
+
+class RtError(RuntimeError):
+    pass
+
+
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class Camera(C.Structure):
+    """rt_camera: what get_ray reads (Main.c:776-803)."""
+    _fields_ = [("pos", Vec3), ("pixel00_loc", Vec3), ("pixel_delta_u", Vec3),
+                ("pixel_delta_v", Vec3), ("defocus_disk_u", Vec3), ("defocus_disk_v", Vec3),
+                ("defocus_angle", C.c_float)]
+
+
+class CameraParams(C.Structure):
+    """rt_camera_params: inputs of update_camera_view (Main.c:839-904)."""
+    _fields_ = [("pos", Vec3), ("target", Vec3), ("up", Vec3), ("vfov", C.c_float),
+                ("defocus_angle", C.c_float), ("focus_dist", C.c_float)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("sphere_tests", C.c_uint64),
+                ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+
+
+class Opts(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("strict_fp", C.c_int32), ("seed", C.c_uint32),
+                ("sample_base", C.c_uint32), ("chunk_spp", C.c_int32), ("tile_rows", C.c_int32),
+                ("part_index", C.c_int32), ("part_count", C.c_int32),
+                ("hit_index_out", C.c_void_p), ("accum_out", C.c_void_p), ("stats", C.c_void_p)]
+
+
+# numpy view of rt_sphere: sphere_t + material_t of the reference (Main.c:53-59, 74-79), 40 bytes
+SPHERE_DTYPE = np.dtype([("center", "<f4", 3), ("radius", "<f4"), ("mat_type", "<i4"),
+                         ("albedo", "<f4", 3), ("fuzz", "<f4"), ("ior", "<f4")])
+assert SPHERE_DTYPE.itemsize == 40
+
+EXPORTS = ["rt_init", "rt_set_world", "rt_render", "rt_render_device", "rt_part_rows",
+           "rt_part_row_at", "rt_camera_setup", "rt_camera_defaults", "rt_height_for",
+           "rt_shutdown", "rt_last_error"]
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile librtmi.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j4"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+
+
+def lib():
+    """Load librtmi.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RtError("%s not built; run raytracer_amd.build() or make -C %s" % (LIB_PATH, CSRC))
+        L = C.CDLL(LIB_PATH)
+        L.rt_init.restype = C.c_int
+        L.rt_init.argtypes = [C.c_int]
+        L.rt_set_world.restype = C.c_int
+        L.rt_set_world.argtypes = [C.c_void_p, C.c_size_t]
+        for f in (L.rt_render, L.rt_render_device):
+            f.restype = C.c_int
+            f.argtypes = [C.POINTER(Camera), C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                          C.POINTER(Opts)]
+        L.rt_part_rows.restype = C.c_uint32
+        L.rt_part_rows.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int]
+        L.rt_part_row_at.restype = C.c_uint32
+        L.rt_part_row_at.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int]
+        L.rt_camera_setup.restype = C.c_int
+        L.rt_camera_setup.argtypes = [C.POINTER(CameraParams), C.c_uint32, C.c_uint32, C.POINTER(Camera)]
+        L.rt_camera_defaults.restype = None
+        L.rt_camera_defaults.argtypes = [C.POINTER(CameraParams)]
+        L.rt_height_for.restype = C.c_uint32
+        L.rt_height_for.argtypes = [C.c_uint32, C.c_float]
+        L.rt_shutdown.restype = None
+        L.rt_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RtError("%s failed (%d): %s" % (what, rc, lib().rt_last_error().decode()))
+
+
+def init(device=0):
+    _check(lib().rt_init(device), "rt_init")
+
+
+def shutdown():
+    lib().rt_shutdown()
+
+
+def set_world(spheres):
+    spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
+    _check(lib().rt_set_world(spheres.ctypes.data, len(spheres)), "rt_set_world")
+
+
+def default_params():
+    p = CameraParams()
+    lib().rt_camera_defaults(C.byref(p))
+    return p
+
+
+def height_for(width, aspect=16.0 / 9.0):
+    return int(lib().rt_height_for(width, aspect))
+
+
+def camera(width, height=None, params=None):
+    """rt_camera for the reference's default view (or `params`) at width x height."""
+    if height is None:
+        height = height_for(width)
+    p = params if params is not None else default_params()
+    cam = Camera()
+    _check(lib().rt_camera_setup(C.byref(p), width, height, C.byref(cam)), "rt_camera_setup")
+    return cam
+
+
+def camera_as_array(cam):
+    return np.frombuffer(bytes(cam), dtype="<f4").copy()
+
+
+def part_rows(height, tile_rows, part_index, part_count):
+    return int(lib().rt_part_rows(height, tile_rows, part_index, part_count))
+
+
+def part_row_map(height, tile_rows, part_index, part_count):
+    """Image rows owned by a part, in the order of its compact buffer."""
+    n = part_rows(height, tile_rows, part_index, part_count)
+    return np.array([lib().rt_part_row_at(k, tile_rows, part_index, part_count) for k in range(n)],
+                    dtype=np.int64)
+
+
+def _opts(mode, strict_fp, seed, sample_base, chunk_spp, tile_rows, part_index, part_count):
+    o = Opts()
+    o.mode, o.strict_fp, o.seed, o.sample_base = mode, int(bool(strict_fp)), seed, sample_base
+    o.chunk_spp, o.tile_rows, o.part_index, o.part_count = chunk_spp, tile_rows, part_index, part_count
+    return o
+
+
+def render(cam, width, height, spp, max_depth, mode=MODE_MC, strict_fp=False, seed=0, sample_base=0,
+           chunk_spp=0, tile_rows=0, part_index=0, part_count=0, want_hit=False, want_accum=False,
+           out=None):
+    """rt_render into host memory.  Returns dict(rgba, hit, accum, stats)."""
+    rgba = out if out is not None else np.zeros((height, width, 4), dtype=np.uint8)
+    assert rgba.dtype == np.uint8 and rgba.shape == (height, width, 4) and rgba.flags.c_contiguous
+    hit = np.full((height, width), -2, dtype=np.int32) if want_hit else None
+    acc = np.zeros((height, width, 3), dtype=np.float32) if want_accum else None
+    st = Stats()
+    o = _opts(mode, strict_fp, seed, sample_base, chunk_spp, tile_rows, part_index, part_count)
+    o.hit_index_out = hit.ctypes.data if want_hit else None
+    o.accum_out = acc.ctypes.data if want_accum else None
+    o.stats = C.addressof(st)
+    _check(lib().rt_render(C.byref(cam), rgba.ctypes.data, width, height, spp, max_depth, C.byref(o)),
+           "rt_render")
+    return dict(rgba=rgba, hit=hit, accum=acc, stats=st)
+
+
+def render_device(cam, rgba_dev_ptr, width, height, spp, max_depth, mode=MODE_MC, strict_fp=False,
+                  seed=0, sample_base=0, chunk_spp=0, tile_rows=0, part_index=0, part_count=0,
+                  hit_dev_ptr=None, accum_dev_ptr=None):
+    """rt_render_device: outputs are raw device pointers (e.g. torch.Tensor.data_ptr())."""
+    st = Stats()
+    o = _opts(mode, strict_fp, seed, sample_base, chunk_spp, tile_rows, part_index, part_count)
+    o.hit_index_out = hit_dev_ptr
+    o.accum_out = accum_dev_ptr
+    o.stats = C.addressof(st)
+    _check(lib().rt_render_device(C.byref(cam), rgba_dev_ptr, width, height, spp, max_depth, C.byref(o)),
+           "rt_render_device")
+    return st

@@ -1,0 +1,376 @@
+// Host side of librtmi.so: the extern "C" entry points declared in include/rt.h.
+// Owns the HIP device, one stream, the structure-of-arrays world and the scratch buffers
+// (per-chunk partial sums, work/ray counters, staging for host-pointer callers).
+#include "../../include/rt.h"
+#include "rt_device.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+using namespace rtmi;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct State {
+    bool inited = false;
+    int device = -1;
+    int num_cu = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // world
+    int n = 0, n_pad = 0;
+    DevBuf geom, matA, matB;
+    // scratch
+    DevBuf partial, counters, rgba, accum, hit;
+    std::vector<uint8_t> h_rgba;
+    std::vector<float> h_accum;
+    std::vector<int32_t> h_hit;
+} g;
+
+char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(e_ == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE,         \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                   \
+    } while (0)
+
+inline void put3(float *d, rt_vec3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+
+struct V3 { float x, y, z; };
+inline V3 V(rt_vec3 a) { return V3{a.x, a.y, a.z}; }
+inline V3 vsub(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 vadd(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 vscale(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+inline V3 vcross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline V3 vunit(V3 v)
+{
+    float len = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    if (len > 0.0f) { float inv = 1.0f / len; return V3{v.x * inv, v.y * inv, v.z * inv}; }
+    return V3{0.0f, 0.0f, 0.0f};
+}
+inline rt_vec3 R(V3 a) { rt_vec3 r; r.x = a.x; r.y = a.y; r.z = a.z; return r; }
+
+// radians_from_turns_f32 / radians_from_degrees_f32, include/util.h:134-139
+inline float turns_to_rad(float v) { return v * (2 * 3.1415926535897f); }
+inline float deg_to_rad(float v) { return turns_to_rad(v / 360.f); }
+
+int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height, int spp,
+                  int max_depth, const rt_opts *opts, bool device_ptrs)
+{
+    using clk = std::chrono::steady_clock;
+    const auto t_start = clk::now();
+    rt_opts dflt;
+    memset(&dflt, 0, sizeof dflt);
+    const rt_opts &o = opts ? *opts : dflt;
+
+    if (!g.inited) return fail(RT_ERR_STATE, "rt_render: rt_init has not been called");
+    if (g.n_pad == 0) return fail(RT_ERR_STATE, "rt_render: rt_set_world has not been called");
+    if (!cam || !rgba) return fail(RT_ERR_ARG, "rt_render: null camera or framebuffer");
+    if (width == 0 || height == 0 || (uint64_t)width * height > 0x7fffffffULL)
+        return fail(RT_ERR_ARG, "rt_render: bad image size %ux%u", width, height);
+    if (spp < 1) return fail(RT_ERR_ARG, "rt_render: spp must be >= 1 (got %d)", spp);
+    if (max_depth < 0) return fail(RT_ERR_ARG, "rt_render: max_depth must be >= 0 (got %d)", max_depth);
+    if (o.mode != RT_MODE_MC && o.mode != RT_MODE_CONST_U) return fail(RT_ERR_ARG, "rt_render: unknown mode %d", o.mode);
+    if (o.chunk_spp < 0 || o.tile_rows < 0) return fail(RT_ERR_ARG, "rt_render: negative chunk_spp or tile_rows");
+    const int part_count = o.part_count > 1 ? o.part_count : 1;
+    const int part_index = part_count > 1 ? o.part_index : 0;
+    if (part_index < 0 || part_index >= part_count) return fail(RT_ERR_ARG, "rt_render: part_index %d outside [0,%d)", o.part_index, part_count);
+    const int tile_rows = o.tile_rows > 0 ? o.tile_rows : 16;
+
+    HIP_TRY(hipSetDevice(g.device));
+
+    const uint32_t rows = rt_part_rows(height, tile_rows, part_index, part_count);
+    const uint32_t npix = rows * width;
+    const int chunk = (o.chunk_spp > 0 && o.chunk_spp < spp) ? o.chunk_spp : spp;
+    const int nchunks = (spp + chunk - 1) / chunk;
+    const uint64_t units = (uint64_t)npix * (uint64_t)nchunks;
+    if (units >= 0xffffffffULL) return fail(RT_ERR_ARG, "rt_render: %llu work units; raise chunk_spp", (unsigned long long)units);
+
+    rt_stats st;
+    memset(&st, 0, sizeof st);
+
+    uint8_t *d_rgba = rgba;
+    float *d_accum = o.accum_out;
+    int32_t *d_hit = o.hit_index_out;
+    if (!device_ptrs) {
+        HIP_TRY(g.rgba.reserve((size_t)npix * 4 + 4));
+        d_rgba = (uint8_t *)g.rgba.p;
+        if (o.accum_out) { HIP_TRY(g.accum.reserve((size_t)npix * 12 + 4)); d_accum = (float *)g.accum.p; }
+        if (o.hit_index_out) { HIP_TRY(g.hit.reserve((size_t)npix * 4 + 4)); d_hit = (int32_t *)g.hit.p; }
+    }
+
+    if (npix > 0) {
+        if (max_depth == 0) {
+            // ray_color's loop does not run: every sample is (0,0,0) (Main.c:730,761).
+            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d_rgba, (int)0xFF000000u, npix, g.stream));   // r=g=b=0, a=255
+            if (d_accum) HIP_TRY(hipMemsetAsync(d_accum, 0, (size_t)npix * 12, g.stream));
+            if (d_hit) HIP_TRY(hipMemsetAsync(d_hit, 0xff, (size_t)npix * 4, g.stream));
+        } else {
+            HIP_TRY(g.partial.reserve((size_t)units * sizeof(float4)));
+            HIP_TRY(hipMemsetAsync(g.counters.p, 0, 2 * sizeof(unsigned long long), g.stream));
+
+            TraceParams tp;
+            memset(&tp, 0, sizeof tp);
+            put3(tp.cam.pos, cam->pos); put3(tp.cam.p00, cam->pixel00_loc);
+            put3(tp.cam.du, cam->pixel_delta_u); put3(tp.cam.dv, cam->pixel_delta_v);
+            put3(tp.cam.ddu, cam->defocus_disk_u); put3(tp.cam.ddv, cam->defocus_disk_v);
+            tp.cam.defocus_angle = cam->defocus_angle;
+            tp.geom = (const float4 *)g.geom.p; tp.matA = (const float4 *)g.matA.p; tp.matB = (const float4 *)g.matB.p;
+            tp.n = g.n; tp.n_pad = g.n_pad;
+            tp.width = width; tp.height = height; tp.npix = npix;
+            tp.tile_rows = tile_rows; tp.part_index = part_index; tp.part_count = part_count;
+            tp.spp = spp; tp.chunk_spp = chunk; tp.nchunks = nchunks; tp.max_depth = max_depth;
+            tp.mode = o.mode; tp.seed = o.seed; tp.sample_base = o.sample_base;
+            tp.partial = (float4 *)g.partial.p;
+            tp.hit_index = d_hit;
+            tp.counters = (unsigned long long *)g.counters.p;
+            tp.total_units = units;
+
+            const size_t lds = ((size_t)g.n_pad + 2 * (size_t)g.n) * sizeof(float4);
+            const int per_cu = o.strict_fp ? trace_blocks_per_cu_strict(lds) : trace_blocks_per_cu_fast(lds);
+            uint64_t blocks = (uint64_t)g.num_cu * (uint64_t)per_cu;
+            const uint64_t need = (units + kBlockThreads - 1) / kBlockThreads;
+            if (blocks > need) blocks = need;
+
+            HIP_TRY(hipEventRecord(g.ev0, g.stream));
+            HIP_TRY(o.strict_fp ? launch_trace_strict(tp, (int)blocks, lds, g.stream)
+                                : launch_trace_fast(tp, (int)blocks, lds, g.stream));
+            ResolveParams rp;
+            rp.partial = (const float4 *)g.partial.p; rp.nchunks = nchunks; rp.npix = npix;
+            rp.inv_spp = (float)1.0f / (float)spp;
+            rp.rgba = d_rgba; rp.accum = d_accum;
+            HIP_TRY(launch_resolve(rp, g.stream));
+            HIP_TRY(hipEventRecord(g.ev1, g.stream));
+        }
+    }
+
+    // read back (host-pointer entry) and/or wait
+    if (!device_ptrs && npix > 0) {
+        g.h_rgba.resize((size_t)npix * 4);
+        HIP_TRY(hipMemcpyAsync(g.h_rgba.data(), d_rgba, (size_t)npix * 4, hipMemcpyDeviceToHost, g.stream));
+        if (o.accum_out) {
+            g.h_accum.resize((size_t)npix * 3);
+            HIP_TRY(hipMemcpyAsync(g.h_accum.data(), d_accum, (size_t)npix * 12, hipMemcpyDeviceToHost, g.stream));
+        }
+        if (o.hit_index_out) {
+            g.h_hit.resize(npix);
+            HIP_TRY(hipMemcpyAsync(g.h_hit.data(), d_hit, (size_t)npix * 4, hipMemcpyDeviceToHost, g.stream));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(g.stream));
+
+    if (!device_ptrs) {
+        for (uint32_t k = 0; k < rows; k++) {
+            const uint32_t y = rt_part_row_at(k, tile_rows, part_index, part_count);
+            memcpy(rgba + (size_t)y * width * 4, g.h_rgba.data() + (size_t)k * width * 4, (size_t)width * 4);
+            if (o.accum_out) memcpy(o.accum_out + (size_t)y * width * 3, g.h_accum.data() + (size_t)k * width * 3, (size_t)width * 12);
+            if (o.hit_index_out) memcpy(o.hit_index_out + (size_t)y * width, g.h_hit.data() + (size_t)k * width, (size_t)width * 4);
+        }
+    }
+
+    if (o.stats) {
+        st.samples = (uint64_t)npix * (uint64_t)spp;
+        if (npix > 0 && max_depth > 0) {
+            unsigned long long c[2] = {0, 0};
+            HIP_TRY(hipMemcpy(c, g.counters.p, sizeof c, hipMemcpyDeviceToHost));
+            st.rays = c[1];
+            st.sphere_tests = c[1] * (uint64_t)g.n;
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, g.ev0, g.ev1));
+            st.kernel_ms = ms;
+        }
+        st.total_ms = std::chrono::duration<double, std::milli>(clk::now() - t_start).count();
+        *o.stats = st;
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_err; }
+
+int rt_init(int device)
+{
+    if (g.inited) rt_shutdown();
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return fail(RT_ERR_DEVICE, "rt_init: no HIP device (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(RT_ERR_ARG, "rt_init: device %d outside [0,%d)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RT_ERR_DEVICE, "rt_init: device %d is %s; this library holds gfx950 code only", device, prop.gcnArchName);
+    g.device = device;
+    g.num_cu = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&g.ev0));
+    HIP_TRY(hipEventCreate(&g.ev1));
+    HIP_TRY(g.counters.reserve(2 * sizeof(unsigned long long)));
+    g.inited = true;
+    g_err[0] = 0;
+    return RT_OK;
+}
+
+int rt_set_world(const rt_sphere *spheres, size_t count)
+{
+    if (!g.inited) return fail(RT_ERR_STATE, "rt_set_world: rt_init has not been called");
+    if (!spheres && count) return fail(RT_ERR_ARG, "rt_set_world: null sphere array");
+    if (count > (size_t)kMaxSpheres)
+        return fail(RT_ERR_ARG, "rt_set_world: %zu spheres; at most %d fit the per-workgroup LDS image", count, kMaxSpheres);
+    for (size_t i = 0; i < count; i++)
+        if (spheres[i].mat_type < RT_MAT_LAMBERTIAN || spheres[i].mat_type > RT_MAT_DIELECTRIC)
+            return fail(RT_ERR_ARG, "rt_set_world: sphere %zu has unsupported material type %d", i, spheres[i].mat_type);
+    HIP_TRY(hipSetDevice(g.device));
+    const int n = (int)count;
+    const int n_pad = n == 0 ? kGeomPad : ((n + kGeomPad - 1) / kGeomPad) * kGeomPad;
+    std::vector<float4> geom(n_pad), matA(n > 0 ? n : 1), matB(n > 0 ? n : 1);
+    for (int i = 0; i < n_pad; i++) {
+        if (i < n) {
+            const rt_sphere &s = spheres[i];
+            geom[i] = make_float4(s.center.x, s.center.y, s.center.z, s.radius * s.radius);   // Main.c:650
+            matA[i] = make_float4(s.albedo.x, s.albedo.y, s.albedo.z, s.fuzz);
+            int32_t mt = s.mat_type;
+            float mtf;
+            memcpy(&mtf, &mt, 4);
+            matB[i] = make_float4(s.refraction_index, mtf, 1.0f / s.radius, s.radius);        // Main.c:679
+        } else {
+            geom[i] = make_float4(0.0f, 0.0f, 0.0f, -std::numeric_limits<float>::infinity());
+        }
+    }
+    HIP_TRY(g.geom.reserve(geom.size() * sizeof(float4)));
+    HIP_TRY(g.matA.reserve(matA.size() * sizeof(float4)));
+    HIP_TRY(g.matB.reserve(matB.size() * sizeof(float4)));
+    HIP_TRY(hipMemcpy(g.geom.p, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g.matA.p, matA.data(), matA.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g.matB.p, matB.data(), matB.size() * sizeof(float4), hipMemcpyHostToDevice));
+    g.n = n;
+    g.n_pad = n_pad;
+    return RT_OK;
+}
+
+int rt_render(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height, int spp, int max_depth,
+              const rt_opts *opts)
+{
+    return render_common(cam, rgba, width, height, spp, max_depth, opts, false);
+}
+
+int rt_render_device(const rt_camera *cam, uint8_t *rgba_dev, uint32_t width, uint32_t height, int spp,
+                     int max_depth, const rt_opts *opts)
+{
+    return render_common(cam, rgba_dev, width, height, spp, max_depth, opts, true);
+}
+
+uint32_t rt_part_rows(uint32_t height, int tile_rows, int part_index, int part_count)
+{
+    if (part_count <= 1) return height;
+    if (part_index < 0 || part_index >= part_count) return 0;
+    const uint32_t tr = tile_rows > 0 ? (uint32_t)tile_rows : 16u;
+    const uint32_t ntiles = (height + tr - 1) / tr;
+    uint32_t rows = 0;
+    for (uint32_t t = (uint32_t)part_index; t < ntiles; t += (uint32_t)part_count) {
+        const uint32_t y0 = t * tr;
+        rows += (y0 + tr > height) ? height - y0 : tr;
+    }
+    return rows;
+}
+
+uint32_t rt_part_row_at(uint32_t k, int tile_rows, int part_index, int part_count)
+{
+    return part_row_at(k, tile_rows > 0 ? tile_rows : 16, part_index, part_count > 1 ? part_count : 1);
+}
+
+void rt_camera_defaults(rt_camera_params *p)
+{
+    if (!p) return;
+    p->pos = rt_vec3{13.0f, 2.0f, 3.0f};        // Main.c:915-922
+    p->target = rt_vec3{0.0f, 0.0f, 0.0f};
+    p->up = rt_vec3{0.0f, 1.0f, 0.0f};
+    p->vfov = 60.0f;
+    p->defocus_angle = 0.6f;
+    p->focus_dist = 10.0f;
+}
+
+uint32_t rt_height_for(uint32_t width, float aspect_ratio)
+{
+    return (uint32_t)((int)width / aspect_ratio);  // Main.c:908
+}
+
+int rt_camera_setup(const rt_camera_params *p, uint32_t width, uint32_t height, rt_camera *out)
+{
+    if (!p || !out || width == 0 || height == 0) return fail(RT_ERR_ARG, "rt_camera_setup: bad argument");
+    const V3 pos = V(p->pos), target = V(p->target), up = V(p->up);
+    const float theta = deg_to_rad(p->vfov);                                  // Main.c:866
+    const float h = tanf(turns_to_rad(theta / 2.0f));                         // Main.c:867, tan_f32 util.h:142
+    const float vp_h = 2.0f * h * p->focus_dist;
+    const float vp_w = vp_h * ((float)width / (float)height);
+    const V3 w = vunit(vsub(pos, target));
+    const V3 u = vunit(vcross(up, w));
+    const V3 v = vcross(w, u);
+    const V3 vp_u = vscale(u, vp_w);
+    const V3 vp_v = vscale(v, -vp_h);
+    const V3 du = vscale(vp_u, 1.0f / (float)width);
+    const V3 dv = vscale(vp_v, 1.0f / (float)height);
+    const V3 centre = vsub(pos, vscale(w, p->focus_dist));
+    const V3 ul = vsub(centre, vadd(vscale(vp_u, 0.5f), vscale(vp_v, 0.5f)));
+    const V3 p00 = vadd(ul, vadd(vscale(du, 0.5f), vscale(dv, 0.5f)));
+    const float radius = p->focus_dist * tanf(turns_to_rad(deg_to_rad(p->defocus_angle / 2)));   // Main.c:900
+    out->pos = p->pos;
+    out->pixel00_loc = R(p00);
+    out->pixel_delta_u = R(du);
+    out->pixel_delta_v = R(dv);
+    out->defocus_disk_u = R(vscale(u, radius));
+    out->defocus_disk_v = R(vscale(v, radius));
+    out->defocus_angle = p->defocus_angle;
+    return RT_OK;
+}
+
+void rt_shutdown(void)
+{
+    if (!g.inited) return;
+    (void)hipSetDevice(g.device);
+    (void)hipStreamSynchronize(g.stream);
+    g.geom.release(); g.matA.release(); g.matB.release();
+    g.partial.release(); g.counters.release(); g.rgba.release(); g.accum.release(); g.hit.release();
+    if (g.ev0) (void)hipEventDestroy(g.ev0);
+    if (g.ev1) (void)hipEventDestroy(g.ev1);
+    if (g.stream) (void)hipStreamDestroy(g.stream);
+    g = State();
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+// Shared declarations between the host side of librtmi.so (rt_api.hip) and its two
+// kernel translation units (rt_trace_strict.hip, rt_trace_fast.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtmi {
+
+// Device-resident world in structure-of-arrays form.  One float4 per sphere and array:
+//   geom[i] = { cx, cy, cz, r*r }            -- all hit_sphere (Main.c:625-653) needs to reject
+//   matA[i] = { albedo.r, albedo.g, albedo.b, fuzz }
+//   matB[i] = { refraction_index, bits(mat_type), 1.0f/r, r }
+// geom is padded to a multiple of kGeomPad with never-hit entries (r*r = -inf).
+constexpr int kGeomPad = 8;
+constexpr int kMaxSpheres = 3072;          // 48 B/sphere of LDS per workgroup: 144 KB of the 160 KB
+constexpr int kBlockThreads = 512;         // 8 waves per workgroup
+
+struct Camera {                            // rt_camera, flattened
+    float pos[3], p00[3], du[3], dv[3], ddu[3], ddv[3];
+    float defocus_angle;
+};
+
+struct TraceParams {
+    Camera cam;
+    const float4 *geom;                    // [n_pad]
+    const float4 *matA;                    // [n]
+    const float4 *matB;                    // [n]
+    int n, n_pad;
+    uint32_t width, height;                // full image
+    uint32_t npix;                         // owned pixels = owned_rows * width
+    int tile_rows, part_index, part_count; // owned row k -> image row, see part_row_at()
+    int spp, chunk_spp, nchunks, max_depth;
+    int mode;                              // RT_MODE_*
+    uint32_t seed, sample_base;
+    float4 *partial;                       // [nchunks][npix] per-chunk colour sums
+    int32_t *hit_index;                    // [npix] compact, or nullptr
+    unsigned long long *counters;          // [0] next work unit, [1] rays cast
+    unsigned long long total_units;        // npix * nchunks
+};
+
+struct ResolveParams {
+    const float4 *partial;
+    int nchunks;
+    uint32_t npix;
+    float inv_spp;                         // (f32)1.0f/(f32)spp, Main.c:977
+    uint8_t *rgba;                         // compact [npix][4]
+    float *accum;                          // compact [npix][3] or nullptr
+};
+
+// Image row of the k-th owned row: row tiles of tile_rows rows are dealt round-robin.
+__host__ __device__ inline uint32_t part_row_at(uint32_t k, int tile_rows, int part_index, int part_count)
+{
+    if (part_count <= 1) return k;
+    uint32_t tr = (uint32_t)tile_rows;
+    uint32_t t = k / tr, r = k % tr;
+    return (t * (uint32_t)part_count + (uint32_t)part_index) * tr + r;
+}
+
+hipError_t launch_trace_strict(const TraceParams &p, int blocks, size_t lds_bytes, hipStream_t s);
+hipError_t launch_trace_fast(const TraceParams &p, int blocks, size_t lds_bytes, hipStream_t s);
+hipError_t launch_resolve(const ResolveParams &p, hipStream_t s);
+int trace_blocks_per_cu_strict(size_t lds_bytes);
+int trace_blocks_per_cu_fast(size_t lds_bytes);
+
+}  // namespace rtmi

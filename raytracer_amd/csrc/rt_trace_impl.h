@@ -1,0 +1,379 @@
+// Path-tracing kernel body, compiled twice:
+//   rt_trace_strict.hip : RT_STRICT 1, -ffp-contract=off, IEEE sqrt and divide.  Every f32
+//                         operation is written in the order the reference writes it, so the
+//                         image is bit-identical to a CPU evaluation of the same expressions.
+//   rt_trace_fast.hip   : RT_STRICT 0, FMA contraction, unit-length ray directions, hardware
+//                         rsqrt/rcp.  Same estimator, not bit-identical.
+//
+// Mapping: one lane = one stream of pixel samples.  A lane owns a work unit (pixel, chunk of
+// samples), traces its samples one after another, and immediately starts the next sample when a
+// path ends, so that every lane of the wave has a live ray whenever the wave enters the sphere
+// loop.  Lanes that run out of samples pull the next unit from a global counter; the wave
+// does that with one ballot, one atomic and a prefix count.
+//
+// Reference functions restated here (file:line under the reference tree):
+//   get_ray Main.c:776-803, sample_square :764, defocus_disk_sample :770,
+//   hit_sphere :625-686, hit :688-713, set_face_normal :534, reflectance :551,
+//   ray_scatter :558-620, ray_color :725-762, render_tile :959-988,
+//   vec3f_* src/util.c:83-220.
+#include "rt_device.h"
+
+#ifndef RT_STRICT
+#error "RT_STRICT must be defined"
+#endif
+
+namespace rtmi {
+namespace RT_NS {
+
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 mul(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 scale(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float lensq(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+
+#if RT_STRICT
+__device__ __forceinline__ float rt_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ float rt_div(float a, float b) { return a / b; }
+__device__ __forceinline__ float rt_inv_sqrt(float x) { return 1.0f / sqrtf(x); }
+#else
+__device__ __forceinline__ float rt_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float rt_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float rt_inv_sqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+#endif
+
+// vec3f_unit, util.c:132-141
+__device__ __forceinline__ V3 unit(V3 v)
+{
+    float l2 = lensq(v);
+#if RT_STRICT
+    float len = rt_sqrt(l2);
+    if (len > 0.0f) {
+        float inv = 1.0f / len;
+        return scale(v, inv);
+    }
+    return v3(0.0f, 0.0f, 0.0f);
+#else
+    float inv = l2 > 0.0f ? rt_inv_sqrt(l2) : 0.0f;
+    return scale(v, inv);
+#endif
+}
+
+// vec3f_reflect, util.c:208-211
+__device__ __forceinline__ V3 reflect(V3 v, V3 n) { return sub(v, scale(n, 2.0f * dot(v, n))); }
+
+// ---- counter-based random numbers ---------------------------------------------------------
+// key  = mix32( mix32(pixel + mix32(seed ^ 0x6A09E667)) ^ sample * 0x9E3779B9 )
+// draw = mix32(key + n * 0x9E3779B9), n = 0, 1, 2, ... per sample;  u = (draw >> 8) * 2^-24
+// Replaces fast_rand / RAND_FLOAT (util.c:27-39, util.h:93).
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
+struct Rng { uint32_t key, n; };
+
+template <int MODE>
+__device__ __forceinline__ float rng_float(Rng &r)
+{
+    if (MODE == 1) return 0.5f;                       // RT_MODE_CONST_U: fast_rand() == 16384
+    uint32_t x = mix32(r.key + r.n * 0x9E3779B9U);
+    r.n++;
+    return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
+// RAND_FLOAT_RANGE(-1, 1), util.h:94
+template <int MODE>
+__device__ __forceinline__ float rng_pm1(Rng &r) { return -1.0f + 2.0f * rng_float<MODE>(r); }
+
+// vec3f_random_direction, util.c:170-184
+template <int MODE>
+__device__ __forceinline__ V3 random_direction(Rng &r)
+{
+    for (int i = 0; i < 100; i++) {
+        V3 p;
+        p.x = rng_pm1<MODE>(r);
+        p.y = rng_pm1<MODE>(r);
+        p.z = rng_pm1<MODE>(r);
+        float l2 = lensq(p);
+        if (1e-15 < (double)l2 && l2 <= 1.0f) return scale(p, rt_inv_sqrt(l2));
+    }
+    return v3(0.0f, 0.0f, 0.0f);
+}
+
+// vec3f_random_direction_2d, util.c:186-200
+template <int MODE>
+__device__ __forceinline__ V3 random_direction_2d(Rng &r)
+{
+    for (int i = 0; i < 100; i++) {
+        V3 p;
+        p.x = rng_pm1<MODE>(r);
+        p.y = rng_pm1<MODE>(r);
+        p.z = 0.0f;
+        float l2 = lensq(p);
+        if (1e-15 < (double)l2 && l2 <= 1.0f) return p;
+    }
+    return v3(0.0f, 0.0f, 0.0f);
+}
+
+// reflectance, Main.c:551-556
+__device__ __forceinline__ float reflectance(float cosine, float ri)
+{
+    float r0 = rt_div(1.0f - ri, 1.0f + ri);
+    r0 = r0 * r0;
+    float m = 1.0f - cosine;
+    return r0 + (1.0f - r0) * (m * m * m * m * m);
+}
+
+// vec3f_refract, util.c:214-220
+__device__ __forceinline__ V3 refract(V3 v, V3 n, float e)
+{
+    float cos_theta = fminf(dot(scale(v, -1.0f), n), 1.0f);
+    V3 perp = scale(add(v, scale(n, cos_theta)), e);
+    V3 par = scale(n, -1.0f * rt_sqrt(fabsf(1.0f - lensq(perp))));
+    return add(perp, par);
+}
+
+struct Lane {
+    // current ray (fast build: d is unit length and tmin carries the original length)
+    V3 o, d;
+    float tmin;
+    bool zero_dir;
+    V3 thr;             // path throughput, "color" in ray_color
+    V3 acc;             // partial sum of the current unit
+    Rng rng;
+    uint32_t pixc;      // compact pixel index of the unit
+    uint32_t x, y;      // image coordinates of that pixel
+    int s, s_end;       // current / one-past-last sample index of the unit
+    int chunk;
+    int bounce;
+};
+
+template <int MODE>
+__device__ __forceinline__ void set_ray(Lane &L, V3 o, V3 d)
+{
+    L.o = o;
+#if RT_STRICT
+    L.d = d;
+    L.tmin = 0.001f;
+    L.zero_dir = false;
+#else
+    float l2 = lensq(d);
+    L.zero_dir = !(l2 > 0.0f);
+    float inv = L.zero_dir ? 0.0f : rt_inv_sqrt(l2);
+    L.d = scale(d, inv);
+    L.tmin = 0.001f * (l2 * inv);     // 0.001 * |d|
+#endif
+}
+
+// get_ray, Main.c:776-803
+template <int MODE>
+__device__ __forceinline__ void camera_ray(const TraceParams &p, Lane &L)
+{
+    const Camera &c = p.cam;
+    float offx = rng_float<MODE>(L.rng) - 0.5f;
+    float offy = rng_float<MODE>(L.rng) - 0.5f;
+    float fx = (float)(int)L.x + offx;
+    float fy = (float)(int)L.y + offy;
+    V3 ps;
+    ps.x = c.p00[0] + (fx * c.du[0]) + (fy * c.dv[0]);
+    ps.y = c.p00[1] + (fx * c.du[1]) + (fy * c.dv[1]);
+    ps.z = c.p00[2] + (fx * c.du[2]) + (fy * c.dv[2]);
+    V3 org = v3(c.pos[0], c.pos[1], c.pos[2]);
+    if (!(c.defocus_angle <= 0.0f)) {
+        V3 q = random_direction_2d<MODE>(L.rng);
+        V3 a = scale(v3(c.ddu[0], c.ddu[1], c.ddu[2]), q.x);
+        V3 b = scale(v3(c.ddv[0], c.ddv[1], c.ddv[2]), q.y);
+        org = add(org, add(a, b));
+    }
+    set_ray<MODE>(L, org, sub(ps, org));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams p)
+{
+    extern __shared__ float4 lds[];
+    float4 *s_geom = lds;                    // [n_pad]
+    float4 *s_matA = lds + p.n_pad;          // [n]
+    float4 *s_matB = s_matA + p.n;           // [n]
+    for (int i = threadIdx.x; i < p.n_pad; i += blockDim.x) s_geom[i] = p.geom[i];
+    for (int i = threadIdx.x; i < p.n; i += blockDim.x) { s_matA[i] = p.matA[i]; s_matB[i] = p.matB[i]; }
+    __syncthreads();
+
+    const uint32_t total = (uint32_t)p.total_units;
+    Lane L;
+    L.acc = v3(0.0f, 0.0f, 0.0f);
+    L.thr = v3(1.0f, 1.0f, 1.0f);
+    L.o = v3(0.0f, 0.0f, 0.0f);
+    L.d = v3(0.0f, 0.0f, 1.0f);
+    L.tmin = 0.001f;
+    L.zero_dir = false;
+    L.rng.key = 0; L.rng.n = 0;
+    L.pixc = 0; L.x = 0; L.y = 0; L.s = 0; L.s_end = 0; L.chunk = 0; L.bounce = 0;
+    bool active = true;        // lane still has (or may get) work
+    bool need_unit = true;     // lane must pull a new work unit
+    bool need_sample = true;   // lane must start a new sample
+    uint32_t rays = 0;
+
+    for (;;) {
+        // ---- pull work units: one atomic per wave ------------------------------------
+        unsigned long long want = __ballot(active && need_unit);
+        if (want != 0ULL) {
+            uint32_t cnt = (uint32_t)__popcll(want);
+            uint32_t base = 0;
+            if ((unsigned)__lane_id() == (unsigned)(__ffsll((long long)want) - 1))
+                base = (uint32_t)atomicAdd(&p.counters[0], (unsigned long long)cnt);
+            base = __shfl(base, __ffsll((long long)want) - 1);
+            if (active && need_unit) {
+                uint32_t rank = (uint32_t)__popcll(want & ((1ULL << __lane_id()) - 1ULL));
+                unsigned long long u64 = (unsigned long long)base + rank;
+                if (u64 >= (unsigned long long)total) {
+                    active = false;
+                } else {
+                    uint32_t u = (uint32_t)u64;
+                    L.chunk = (int)(u / p.npix);
+                    L.pixc = u - (uint32_t)L.chunk * p.npix;
+                    uint32_t rowk = L.pixc / p.width;
+                    L.x = L.pixc - rowk * p.width;
+                    L.y = part_row_at(rowk, p.tile_rows, p.part_index, p.part_count);
+                    L.s = L.chunk * p.chunk_spp;
+                    int e = L.s + p.chunk_spp;
+                    L.s_end = e < p.spp ? e : p.spp;
+                    L.acc = v3(0.0f, 0.0f, 0.0f);
+                }
+                need_unit = false;
+            }
+        }
+        if (__ballot(active) == 0ULL) break;
+
+        // ---- start a new sample where the previous path ended ------------------------
+        if (active && need_sample) {
+            uint32_t pix_full = L.x + L.y * p.width;
+            uint32_t h1 = mix32(p.seed ^ 0x6A09E667U);
+            uint32_t h2 = mix32(pix_full + h1);
+            L.rng.key = mix32(h2 ^ ((p.sample_base + (uint32_t)L.s) * 0x9E3779B9U));
+            L.rng.n = 0;
+            camera_ray<MODE>(p, L);
+            L.thr = v3(1.0f, 1.0f, 1.0f);
+            L.bounce = 0;
+            need_sample = false;
+        }
+
+        // ---- hit(): nearest sphere along the ray, Main.c:688-713 -----------------------
+        float closest = 3.402823466e+38f;      // max_f32
+        int hit = -1;
+        {
+            const float ox = L.o.x, oy = L.o.y, oz = L.o.z;
+            const float dx = L.d.x, dy = L.d.y, dz = L.d.z;
+            const float tmin = L.tmin;
+#if RT_STRICT
+            const float a = dx * dx + dy * dy + dz * dz;
+#endif
+#pragma unroll 4
+            for (int i = 0; i < p.n_pad; i++) {
+                const float4 g = s_geom[i];
+                const float ocx = g.x - ox, ocy = g.y - oy, ocz = g.z - oz;
+#if RT_STRICT
+                const float h = dx * ocx + dy * ocy + dz * ocz;
+                const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - g.w;
+                const float disc = h * h - a * c;
+                if (!(disc < 0.0f)) {
+                    const float sq = rt_sqrt(disc);
+                    float root = (h - sq) / a;
+                    bool ok = (tmin < root) && (root < closest);
+                    if (!ok) {
+                        root = (h + sq) / a;
+                        ok = (tmin < root) && (root < closest);
+                    }
+                    if (ok) { closest = root; hit = i; }
+                }
+#else
+                const float h = fmaf(dz, ocz, fmaf(dy, ocy, dx * ocx));
+                const float negc = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, g.w)));
+                const float disc = fmaf(h, h, negc);
+                if (disc >= 0.0f) {
+                    const float sq = rt_sqrt(disc);
+                    const float t0 = h - sq;
+                    const float t = (t0 > tmin) ? t0 : (h + sq);
+                    if (t > tmin && t < closest) { closest = t; hit = i; }
+                }
+#endif
+            }
+            if (L.zero_dir) hit = -1;
+        }
+
+        // ---- shade: ray_color's loop body, Main.c:730-759 ------------------------------
+        if (active) {
+            rays++;
+            if (p.hit_index != nullptr && L.bounce == 0 && L.s == p.spp - 1) p.hit_index[L.pixc] = hit;
+            bool done = false;
+            V3 add_col = v3(0.0f, 0.0f, 0.0f);
+            if (hit >= 0) {
+                const float4 g = s_geom[hit];
+                const float4 mA = s_matA[hit];
+                const float4 mB = s_matB[hit];
+                const V3 ctr = v3(g.x, g.y, g.z);
+                const V3 P = add(L.o, scale(L.d, closest));                 // RAY_AT
+                const V3 outward = scale(sub(P, ctr), mB.z);                // * (1.0f / radius)
+                const bool front = dot(L.d, outward) < 0.0f;                // set_face_normal
+                const V3 n = front ? outward : scale(outward, -1.0f);
+                const int mtype = __float_as_int(mB.y);
+                V3 nd;
+                bool attenuate = true;
+                V3 att = v3(mA.x, mA.y, mA.z);
+                if (mtype == 0) {                                           // Lambertian, Main.c:562-573
+                    nd = add(n, random_direction<MODE>(L.rng));
+                    const float s = 1e-8f;
+                    if (fabsf(nd.x) < s && fabsf(nd.y) < s && fabsf(nd.z) < s) nd = n;
+                } else if (mtype == 1) {                                    // Metal, Main.c:575-581
+                    V3 refl = reflect(L.d, n);
+                    nd = add(unit(refl), scale(random_direction<MODE>(L.rng), mA.w));
+                    attenuate = dot(nd, n) > 0.0f;
+                } else {                                                    // Dielectric, Main.c:583-611
+                    att = v3(1.0f, 1.0f, 1.0f);
+                    const float ri = front ? rt_div(1.0f, mB.x) : mB.x;
+                    const V3 ud = unit(L.d);
+                    const float cos_theta = fminf(dot(scale(ud, -1.0f), n), 1.0f);
+                    const float sin_theta = rt_sqrt(1.0f - cos_theta * cos_theta);
+                    bool refl = ri * sin_theta > 1.0f;
+                    if (!refl) refl = reflectance(cos_theta, ri) > rng_float<MODE>(L.rng);
+                    nd = refl ? reflect(ud, n) : refract(ud, n, ri);
+                }
+                if (attenuate) L.thr = mul(L.thr, att);                     // Main.c:738-742
+                set_ray<MODE>(L, P, nd);
+                L.bounce++;
+                if (L.bounce >= p.max_depth) done = true;                   // Main.c:761: black
+            } else {                                                        // sky, Main.c:744-758
+                const V3 ud = unit(L.d);
+                const float t = 0.5f * (ud.y + 1.0f);
+                const float w = 1.0f - t;
+                const V3 sky = v3(1.0f * w + 0.5f * t, 1.0f * w + 0.7f * t, 1.0f * w + 1.0f * t);
+                add_col = mul(L.thr, sky);
+                done = true;
+            }
+            if (done) {
+                L.acc = add(L.acc, add_col);                                // Main.c:975
+                L.s++;
+                need_sample = true;
+                if (L.s >= L.s_end) {
+                    p.partial[(size_t)L.chunk * p.npix + L.pixc] = make_float4(L.acc.x, L.acc.y, L.acc.z, 0.0f);
+                    need_unit = true;
+                }
+            }
+        }
+    }
+
+    // ---- statistics: rays cast ---------------------------------------------------------
+    unsigned long long r64 = rays;
+    for (int off = 32; off > 0; off >>= 1) r64 += __shfl_down(r64, off);
+    if (__lane_id() == 0) atomicAdd(&p.counters[1], r64);
+}
+
+}  // namespace RT_NS
+}  // namespace rtmi
