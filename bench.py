@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s (pixels x spp per second) on the RTIOW final scene,
+3840x2160, 1000 spp, depth 50 (BASELINE.json configs[3]), on 1..8 MI355X.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  A step = one full frame: every rank path-traces its interleaved row
+tiles with the HIP kernel (through the C ABI, device-resident output), the rows are gathered
+to rank 0 over RCCL and scattered into the full RGBA8 framebuffer on GPU 0.  The image is
+fixed as N grows (strong scaling).  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3      # MI355X vector FP32: 256 CU x 256 flop/clk x 2.4 GHz
+FLOP_PER_TEST = 18            # hit_sphere's miss path (Main.c:628-654) with |d|^2 hoisted per ray
+
+
+def cpu_baseline(width, spp, depth, threads):
+    """The reference's own code (oracle/_ref, built from /root/reference in the build container)
+    timed on this host; falls back to the CPU port when that binary did not travel."""
+    from oracle import refcpu as rc
+    height = rc.height_for(width)
+    samples = width * height * spp
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness_sf")
+    sample = "final scene %dx%d, %d spp (of 1000), depth %d, %d threads over 64x64 tiles" % (
+        width, height, spp, depth, threads)
+    if os.path.exists(exe):
+        with tempfile.NamedTemporaryFile(suffix=".rgba") as f:
+            t0 = time.perf_counter()
+            subprocess.check_call([exe, "mc", str(width), str(spp), str(depth), f.name, str(threads)],
+                                  stderr=subprocess.DEVNULL)
+            dt = time.perf_counter() - t0
+        kind = "reference"
+    else:
+        sph = np.fromfile(os.path.join(ROOT, "tests", "golden", "scene_sf.bin"), dtype=rc.SPHERE_DTYPE)
+        t0 = time.perf_counter()
+        rc.render(rc.camera(width, height), sph, width, height, spp, depth, rng=rc.RNG_LCG_TILES,
+                  threads=threads)
+        dt = time.perf_counter() - t0
+        kind = "port"
+    return {"value": round(samples / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": kind,
+            "sample": sample, "seconds": round(dt, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="sf", choices=["sf", "s3"])
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--spp", type=int, default=1000)
+    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--chunk", type=int, default=50, help="samples per work unit")
+    ap.add_argument("--tile-rows", type=int, default=16)
+    ap.add_argument("--strict", type=int, default=0, help="1 = bit-reproducible build (no FMA)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-width", type=int, default=3840)
+    ap.add_argument("--cpu-spp", type=int, default=1)
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import raytracer_amd as rt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)"
+                         % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible; the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    W = args.width
+    H = rt.height_for(W)
+    sph = np.fromfile(os.path.join(ROOT, "tests", "golden", "scene_%s.bin" % args.scene), dtype=rt.SPHERE_DTYPE)
+    rt.init(local)
+    rt.set_world(sph)
+    cam = rt.camera(W, H)
+
+    from raytracer_amd.multigpu import RowGather
+    rows = [rt.part_row_map(H, args.tile_rows, i, world) for i in range(world)]
+    rg = RowGather(rows, W, 4, torch.uint8, dev, rank, world)    # compact owned rows -> full image on rank 0
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        st = rt.render_device(cam, rg.mine.data_ptr(), W, H, args.spp, args.depth, strict_fp=bool(args.strict),
+                              seed=0, chunk_spp=args.chunk, tile_rows=args.tile_rows,
+                              part_index=rank, part_count=world)
+        rg.gather()                                                   # RCCL over xGMI when world > 1
+        return st
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    stats = [step() for _ in range(args.steps)]
+    sync()
+    dt = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        img = rg.full.cpu().numpy()
+        assert (img[..., 3] == 255).all(), "framebuffer not fully written"
+        samples = W * H * args.spp
+        kernel_ms = float(np.mean([s.kernel_ms for s in stats]))                 # HIP events on the library's stream
+        tests = float(np.mean([s.sphere_tests for s in stats]))
+        rays = float(np.mean([s.rays for s in stats]))
+        own_samples = float(np.mean([s.samples for s in stats]))
+        achieved = FLOP_PER_TEST * tests / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "Msamples/s (px*spp/s) RTIOW final scene" if args.scene == "sf" else "Msamples/s (px*spp/s) 3-sphere scene",
+            "value": round(samples * args.steps / dt / 1e6, 3),
+            "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (the reference's generated %d-sphere scene, committed fixture)" % len(sph),
+            "config": {"workload": "RTIOW %s scene %dx%d, %d spp, depth %d" % (
+                           "final" if args.scene == "sf" else "3-sphere", W, H, args.spp, args.depth),
+                       "spheres": int(len(sph)), "chunk_spp": args.chunk, "tile_rows": args.tile_rows,
+                       "kernel": "strict" if args.strict else "fast",
+                       "parallelism": "row-tiles x%d, RCCL gather to rank 0" % world},
+            "roofline": {"bound": "valu_fp32", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                         "kernel": "trace_kernel", "kernel_ms": round(kernel_ms, 3),
+                         "flop_per_sphere_test": FLOP_PER_TEST,
+                         "sphere_tests_per_launch": tests, "rays_per_sample": round(rays / own_samples, 4)},
+            "kernel_only_msamples_per_s": round(own_samples / kernel_ms / 1e3, 3),
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_width, args.cpu_spp, args.depth, args.cpu_threads)
+        print(json.dumps(out), flush=True)
+
+    rt.shutdown()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -75,8 +75,9 @@ typedef struct rt_stats {
     uint64_t samples;        /* pixel samples traced by this call                  */
     uint64_t rays;           /* calls of hit() (Main.c:688), i.e. rays cast         */
     uint64_t sphere_tests;   /* rays * number of spheres (hit_sphere calls)         */
-    double   kernel_ms;      /* device time of the path-tracing kernel(s), HIP events */
+    double   kernel_ms;      /* device time of the path-tracing kernel, HIP events  */
     double   total_ms;       /* wall time of the call                               */
+    double   resolve_ms;     /* device time of the chunk-sum / gamma / RGBA8 kernel */
 } rt_stats;
 
 typedef struct rt_opts {

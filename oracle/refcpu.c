@@ -490,6 +490,7 @@ int refcpu_render(const rt_camera *cam, const rt_sphere *spheres, size_t count,
         opts->stats->rays = p.rays;
         opts->stats->sphere_tests = p.rays * (uint64_t)count;
         opts->stats->kernel_ms = 0.0;
+        opts->stats->resolve_ms = 0.0;
         opts->stats->total_ms = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
     }
     return RT_OK;

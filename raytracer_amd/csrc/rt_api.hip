@@ -37,7 +37,7 @@ struct State {
     int device = -1;
     int num_cu = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     // world
     int n = 0, n_pad = 0;
     DevBuf geom, matA, matB;
@@ -168,12 +168,13 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
             HIP_TRY(hipEventRecord(g.ev0, g.stream));
             HIP_TRY(o.strict_fp ? launch_trace_strict(tp, (int)blocks, lds, g.stream)
                                 : launch_trace_fast(tp, (int)blocks, lds, g.stream));
+            HIP_TRY(hipEventRecord(g.ev1, g.stream));
             ResolveParams rp;
             rp.partial = (const float4 *)g.partial.p; rp.nchunks = nchunks; rp.npix = npix;
             rp.inv_spp = (float)1.0f / (float)spp;
             rp.rgba = d_rgba; rp.accum = d_accum;
             HIP_TRY(launch_resolve(rp, g.stream));
-            HIP_TRY(hipEventRecord(g.ev1, g.stream));
+            HIP_TRY(hipEventRecord(g.ev2, g.stream));
         }
     }
 
@@ -211,6 +212,8 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
             float ms = 0.0f;
             HIP_TRY(hipEventElapsedTime(&ms, g.ev0, g.ev1));
             st.kernel_ms = ms;
+            HIP_TRY(hipEventElapsedTime(&ms, g.ev1, g.ev2));
+            st.resolve_ms = ms;
         }
         st.total_ms = std::chrono::duration<double, std::milli>(clk::now() - t_start).count();
         *o.stats = st;
@@ -241,6 +244,7 @@ int rt_init(int device)
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&g.ev0));
     HIP_TRY(hipEventCreate(&g.ev1));
+    HIP_TRY(hipEventCreate(&g.ev2));
     HIP_TRY(g.counters.reserve(2 * sizeof(unsigned long long)));
     g.inited = true;
     g_err[0] = 0;
@@ -369,6 +373,7 @@ void rt_shutdown(void)
     g.partial.release(); g.counters.release(); g.rgba.release(); g.accum.release(); g.hit.release();
     if (g.ev0) (void)hipEventDestroy(g.ev0);
     if (g.ev1) (void)hipEventDestroy(g.ev1);
+    if (g.ev2) (void)hipEventDestroy(g.ev2);
     if (g.stream) (void)hipStreamDestroy(g.stream);
     g = State();
 }

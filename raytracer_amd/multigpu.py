@@ -1,0 +1,36 @@
+"""Row-tile gather for the one-process-per-GPU layout.
+
+Each rank path-traces the row tiles t with t % world == rank into a COMPACT buffer
+(rt_render_device with part_index/part_count); gather_rows() moves every rank's rows to
+rank 0 with one torch.distributed gather (RCCL over xGMI with the "nccl" backend, gloo on
+CPU in the tests) and scatters them into the full framebuffer.  There is no reduction:
+row tiles are disjoint.  The reference has no counterpart (single process, Main.c:990-1054).
+"""
+import torch
+import torch.distributed as dist
+
+
+class RowGather:
+    def __init__(self, row_maps, width, channels, dtype, device, rank, world):
+        """row_maps[i] = image rows owned by rank i (ascending), e.g. raytracer_amd.part_row_map."""
+        self.rank, self.world = rank, world
+        self.counts = [len(r) for r in row_maps]
+        self.max_rows = max(self.counts) if self.counts else 0
+        height = sum(self.counts)
+        # every rank sends a buffer of the same shape: pad to the largest part
+        self.mine = torch.zeros((self.max_rows, width, channels), dtype=dtype, device=device)
+        self.full = torch.zeros((height, width, channels), dtype=dtype, device=device) if rank == 0 else None
+        self.recv = ([torch.zeros_like(self.mine) for _ in range(world)]
+                     if (rank == 0 and world > 1) else None)
+        self.idx = [torch.as_tensor(r, dtype=torch.int64, device=device) for r in row_maps] if rank == 0 else None
+
+    def gather(self):
+        """Collect self.mine from all ranks into self.full on rank 0."""
+        if self.world > 1:
+            dist.gather(self.mine, self.recv, dst=0)
+            if self.rank == 0:
+                for i in range(self.world):
+                    self.full.index_copy_(0, self.idx[i], self.recv[i][:self.counts[i]])
+        else:
+            self.full.index_copy_(0, self.idx[0], self.mine[:self.counts[0]])
+        return self.full
