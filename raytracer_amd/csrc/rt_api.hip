@@ -4,6 +4,7 @@
 #include "../../include/rt.h"
 #include "rt_device.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -40,7 +41,10 @@ struct State {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     // world
     int n = 0, n_pad = 0;
-    DevBuf geom, matA, matB;
+    int nbig = 0;
+    int big[kMaxBig] = {0};
+    float c_near = 0.0f;
+    DevBuf geom, matA, matB, pairs;
     // scratch
     DevBuf partial, counters, rgba, accum, hit;
     std::vector<uint8_t> h_rgba;
@@ -149,7 +153,9 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
             put3(tp.cam.ddu, cam->defocus_disk_u); put3(tp.cam.ddv, cam->defocus_disk_v);
             tp.cam.defocus_angle = cam->defocus_angle;
             tp.geom = (const float4 *)g.geom.p; tp.matA = (const float4 *)g.matA.p; tp.matB = (const float4 *)g.matB.p;
+            tp.pairs = (const float *)g.pairs.p;
             tp.n = g.n; tp.n_pad = g.n_pad;
+            tp.nbig = g.nbig; memcpy(tp.big, g.big, sizeof tp.big); tp.c_near = g.c_near;
             tp.width = width; tp.height = height; tp.npix = npix;
             tp.tile_rows = tile_rows; tp.part_index = part_index; tp.part_count = part_count;
             tp.spp = spp; tp.chunk_spp = chunk; tp.nchunks = nchunks; tp.max_depth = max_depth;
@@ -159,7 +165,9 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
             tp.counters = (unsigned long long *)g.counters.p;
             tp.total_units = units;
 
-            const size_t lds = ((size_t)g.n_pad + 2 * (size_t)g.n) * sizeof(float4);
+            const size_t lds = o.strict_fp
+                ? ((size_t)g.n_pad + 2 * (size_t)g.n) * sizeof(float4)
+                : (size_t)g.n_pad * sizeof(float4) + (size_t)(kBlockThreads / 64) * kQueueSlots * 64 * sizeof(uint32_t);
             const int per_cu = o.strict_fp ? trace_blocks_per_cu_strict(lds) : trace_blocks_per_cu_fast(lds);
             uint64_t blocks = (uint64_t)g.num_cu * (uint64_t)per_cu;
             const uint64_t need = (units + kBlockThreads - 1) / kBlockThreads;
@@ -277,6 +285,41 @@ int rt_set_world(const rt_sphere *spheres, size_t count)
             geom[i] = make_float4(0.0f, 0.0f, 0.0f, -std::numeric_limits<float>::infinity());
         }
     }
+    // Fast build's filter data.  A sphere is "big" when its extent |C| + r exceeds four times the
+    // median extent (at most kMaxBig of them, the largest first).
+    std::vector<double> extent(n > 0 ? n : 1, 0.0);
+    for (int i = 0; i < n; i++) {
+        const rt_sphere &s = spheres[i];
+        extent[i] = std::sqrt((double)s.center.x * s.center.x + (double)s.center.y * s.center.y +
+                              (double)s.center.z * s.center.z) + std::fabs((double)s.radius);
+    }
+    std::vector<double> sorted(extent.begin(), extent.begin() + n);
+    std::sort(sorted.begin(), sorted.end());
+    double big_from = n > 0 ? 4.0 * sorted[n / 2] : 0.0;
+    if (n > kMaxBig && big_from < sorted[n - kMaxBig - 1]) big_from = sorted[n - kMaxBig - 1];
+    int nbig = 0;
+    int big[kMaxBig] = {0};
+    std::vector<char> is_big(n_pad, 0);
+    for (int i = 0; i < n && nbig < kMaxBig; i++)
+        if (extent[i] > big_from && n > 1) { is_big[i] = 1; big[nbig++] = i; }
+    double c_near = 0.0;
+    std::vector<float> pairs((size_t)n_pad * 4);
+    for (int i = 0; i < n_pad; i++) {
+        float *q = &pairs[(size_t)(i / 2) * 8 + (i & 1)];
+        const float inf = std::numeric_limits<float>::infinity();
+        if (i < n && !is_big[i]) {
+            const rt_sphere &s = spheres[i];
+            const double c2 = (double)s.center.x * s.center.x + (double)s.center.y * s.center.y +
+                              (double)s.center.z * s.center.z;
+            q[0] = s.center.x; q[2] = s.center.y; q[4] = s.center.z;
+            q[6] = (float)(c2 - (double)s.radius * s.radius);
+            if (std::sqrt(c2) > c_near) c_near = std::sqrt(c2);
+        } else {
+            q[0] = 0.0f; q[2] = 0.0f; q[4] = 0.0f; q[6] = inf;       // never passes the filter
+        }
+    }
+    HIP_TRY(g.pairs.reserve(pairs.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(g.pairs.p, pairs.data(), pairs.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(g.geom.reserve(geom.size() * sizeof(float4)));
     HIP_TRY(g.matA.reserve(matA.size() * sizeof(float4)));
     HIP_TRY(g.matB.reserve(matB.size() * sizeof(float4)));
@@ -285,6 +328,9 @@ int rt_set_world(const rt_sphere *spheres, size_t count)
     HIP_TRY(hipMemcpy(g.matB.p, matB.data(), matB.size() * sizeof(float4), hipMemcpyHostToDevice));
     g.n = n;
     g.n_pad = n_pad;
+    g.nbig = nbig;
+    memcpy(g.big, big, sizeof big);
+    g.c_near = (float)c_near;
     return RT_OK;
 }
 
@@ -369,7 +415,7 @@ void rt_shutdown(void)
     if (!g.inited) return;
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
-    g.geom.release(); g.matA.release(); g.matB.release();
+    g.geom.release(); g.matA.release(); g.matB.release(); g.pairs.release();
     g.partial.release(); g.counters.release(); g.rgba.release(); g.accum.release(); g.hit.release();
     if (g.ev0) (void)hipEventDestroy(g.ev0);
     if (g.ev1) (void)hipEventDestroy(g.ev1);

@@ -12,7 +12,20 @@ namespace rtmi {
 //   matB[i] = { refraction_index, bits(mat_type), 1.0f/r, r }
 // geom is padded to a multiple of kGeomPad with never-hit entries (r*r = -inf).
 constexpr int kGeomPad = 8;
-constexpr int kMaxSpheres = 3072;          // 48 B/sphere of LDS per workgroup: 144 KB of the 160 KB
+// Fast build: the scan over the sphere list is a conservative filter, two spheres per packed-FP32
+// instruction.  pairs[k] holds spheres 2k and 2k+1 as { cx0, cx1, cy0, cy1, cz0, cz1, k0, k1 } with
+// k = |C|^2 - r^2 (read through the scalar cache: the index is wave-uniform).  With a unit
+// direction d, the discriminant h^2 - c >= 0 is (d.C - d.O)^2 + 2 O.C - |O|^2 >= |C|^2 - r^2:
+// seven packed FMAs per pair.  The expanded form cancels badly, so it is compared against a
+// threshold lowered by a bound of its rounding error (it may pass a sphere the ray misses, never
+// the reverse); lanes queue the indices that pass in LDS (kQueueSlots per lane) and the exact
+// test, in the reference's (C - O) form, runs on the queued spheres after the scan.  Spheres far
+// larger than the rest (the r = 1000 ground) would inflate that bound for every sphere, so they
+// are kept out of the filter (k = +inf) and tested exactly for every ray: big[] lists them.
+constexpr int kQueueSlots = 16;
+constexpr int kMaxBig = 16;
+constexpr int kPairBatch = 4;              // pairs per unrolled batch; kGeomPad == 2 * kPairBatch
+constexpr int kMaxSpheres = 2048;          // 48 B/sphere of LDS per workgroup (96 KB) + 32 KB of queues
 constexpr int kBlockThreads = 512;         // 8 waves per workgroup
 
 struct Camera {                            // rt_camera, flattened
@@ -25,7 +38,11 @@ struct TraceParams {
     const float4 *geom;                    // [n_pad]
     const float4 *matA;                    // [n]
     const float4 *matB;                    // [n]
+    const float *pairs;                    // [n_pad / 2][8]
     int n, n_pad;
+    int nbig;                              // spheres tested exactly for every ray
+    int big[kMaxBig];
+    float c_near;                          // max |C| over the filtered spheres
     uint32_t width, height;                // full image
     uint32_t npix;                         // owned pixels = owned_rows * width
     int tile_rows, part_index, part_count; // owned row k -> image row, see part_row_at()

@@ -140,6 +140,74 @@ __device__ __forceinline__ V3 refract(V3 v, V3 n, float e)
     return add(perp, par);
 }
 
+#if !RT_STRICT
+// Fast build: the reference's rejection samplers (util.c:170-200) are replaced by direct maps
+// with the same distributions (uniform on the unit sphere / in the unit disk); no loop, so the
+// lanes of a wave do not wait for the slowest rejection chain.  v_sin/v_cos take revolutions.
+// In constant-u mode the reference's loops reject u = 0.5 a hundred times and return zero.
+template <int MODE>
+__device__ __forceinline__ V3 sphere_direction(Rng &r)
+{
+    if (MODE == 1) return v3(0.0f, 0.0f, 0.0f);
+    const float z = fmaf(-2.0f, rng_float<MODE>(r), 1.0f);
+    const float phi = rng_float<MODE>(r);
+    const float rad = rt_sqrt(fmaxf(0.0f, fmaf(-z, z, 1.0f)));
+    return v3(rad * __builtin_amdgcn_cosf(phi), rad * __builtin_amdgcn_sinf(phi), z);
+}
+
+template <int MODE>
+__device__ __forceinline__ void disk_point(Rng &r, float &x, float &y)
+{
+    if (MODE == 1) { x = 0.0f; y = 0.0f; return; }
+    const float rad = rt_sqrt(rng_float<MODE>(r));
+    const float phi = rng_float<MODE>(r);
+    x = rad * __builtin_amdgcn_cosf(phi);
+    y = rad * __builtin_amdgcn_sinf(phi);
+}
+
+// q = u / n, r = u % n for u < 2^32 without the 32-bit integer divide sequence: the f64
+// product is at most one below the quotient.
+__device__ __forceinline__ void divmod(uint32_t u, uint32_t n, double inv_n, uint32_t &q, uint32_t &r)
+{
+    q = (uint32_t)((double)u * inv_n);
+    r = u - q * n;
+    if (r >= n) { q++; r -= n; }
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(4))) f8 const_f8;      // scalar-cache loads
+
+// One candidate sphere against the lane's ray: the fast build's form of hit_sphere's
+// accept step (Main.c:659-671) for a unit-length direction (a == 1).
+__device__ __forceinline__ void accept(float h, float disc, float tmin, int i, float &closest, int &hit)
+{
+    const float sq = rt_sqrt(disc);
+    const float t0 = h - sq;
+    const float t = (t0 > tmin) ? t0 : (h + sq);
+    if (t > tmin && t < closest) { closest = t; hit = i; }
+}
+
+// Resolve the queued candidates of every lane of the wave.  queue[j * 64 + lane] is the j-th
+// sphere index the lane queued.
+__device__ __forceinline__ void drain(const float4 *s_geom, const uint32_t *queue, int cnt, int lane,
+                                      float ox, float oy, float oz, float dx, float dy, float dz,
+                                      float tmin, float &closest, int &hit)
+{
+    for (int j = 0; __ballot(j < cnt) != 0ULL; j++) {
+        if (j < cnt) {
+            const int i = (int)queue[j * 64 + lane];
+            const float4 g = s_geom[i];
+            const float ocx = g.x - ox, ocy = g.y - oy, ocz = g.z - oz;
+            const float h = fmaf(dz, ocz, fmaf(dy, ocy, dx * ocx));
+            const float negc = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, g.w)));
+            const float disc = fmaf(h, h, negc);
+            if (disc >= 0.0f) accept(h, disc, tmin, i, closest, hit);
+        }
+    }
+}
+#endif
+
 struct Lane {
     // current ray (fast build: d is unit length and tmin carries the original length)
     V3 o, d;
@@ -148,6 +216,7 @@ struct Lane {
     V3 thr;             // path throughput, "color" in ray_color
     V3 acc;             // partial sum of the current unit
     Rng rng;
+    uint32_t pixhash;   // mix32(pixel + mix32(seed ^ c)): the per-pixel part of the sample key
     uint32_t pixc;      // compact pixel index of the unit
     uint32_t x, y;      // image coordinates of that pixel
     int s, s_end;       // current / one-past-last sample index of the unit
@@ -187,7 +256,12 @@ __device__ __forceinline__ void camera_ray(const TraceParams &p, Lane &L)
     ps.z = c.p00[2] + (fx * c.du[2]) + (fy * c.dv[2]);
     V3 org = v3(c.pos[0], c.pos[1], c.pos[2]);
     if (!(c.defocus_angle <= 0.0f)) {
+#if RT_STRICT
         V3 q = random_direction_2d<MODE>(L.rng);
+#else
+        V3 q = v3(0.0f, 0.0f, 0.0f);
+        disk_point<MODE>(L.rng, q.x, q.y);
+#endif
         V3 a = scale(v3(c.ddu[0], c.ddu[1], c.ddu[2]), q.x);
         V3 b = scale(v3(c.ddv[0], c.ddv[1], c.ddv[2]), q.y);
         org = add(org, add(a, b));
@@ -200,13 +274,25 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
 {
     extern __shared__ float4 lds[];
     float4 *s_geom = lds;                    // [n_pad]
+    for (int i = threadIdx.x; i < p.n_pad; i += blockDim.x) s_geom[i] = p.geom[i];
+#if RT_STRICT
     float4 *s_matA = lds + p.n_pad;          // [n]
     float4 *s_matB = s_matA + p.n;           // [n]
-    for (int i = threadIdx.x; i < p.n_pad; i += blockDim.x) s_geom[i] = p.geom[i];
     for (int i = threadIdx.x; i < p.n; i += blockDim.x) { s_matA[i] = p.matA[i]; s_matB[i] = p.matB[i]; }
+#else
+    // The fast build spends its LDS on the candidate queues (more resident waves); the material
+    // records are read once per bounce, from global memory through the vector L1.
+    const float4 *s_matA = p.matA;
+    const float4 *s_matB = p.matB;
+    const int lane = (int)__lane_id();
+    uint32_t *queue = reinterpret_cast<uint32_t *>(lds + p.n_pad) + (threadIdx.x >> 6) * (kQueueSlots * 64);
+#endif
     __syncthreads();
 
     const uint32_t total = (uint32_t)p.total_units;
+#if !RT_STRICT
+    const double inv_npix = 1.0 / (double)p.npix, inv_width = 1.0 / (double)p.width;
+#endif
     Lane L;
     L.acc = v3(0.0f, 0.0f, 0.0f);
     L.thr = v3(1.0f, 1.0f, 1.0f);
@@ -214,7 +300,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
     L.d = v3(0.0f, 0.0f, 1.0f);
     L.tmin = 0.001f;
     L.zero_dir = false;
-    L.rng.key = 0; L.rng.n = 0;
+    L.rng.key = 0; L.rng.n = 0; L.pixhash = 0;
     L.pixc = 0; L.x = 0; L.y = 0; L.s = 0; L.s_end = 0; L.chunk = 0; L.bounce = 0;
     bool active = true;        // lane still has (or may get) work
     bool need_unit = true;     // lane must pull a new work unit
@@ -237,11 +323,19 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
                     active = false;
                 } else {
                     uint32_t u = (uint32_t)u64;
+#if RT_STRICT
                     L.chunk = (int)(u / p.npix);
                     L.pixc = u - (uint32_t)L.chunk * p.npix;
                     uint32_t rowk = L.pixc / p.width;
                     L.x = L.pixc - rowk * p.width;
+#else
+                    uint32_t chunk_u, rowk;
+                    divmod(u, p.npix, inv_npix, chunk_u, L.pixc);
+                    divmod(L.pixc, p.width, inv_width, rowk, L.x);
+                    L.chunk = (int)chunk_u;
+#endif
                     L.y = part_row_at(rowk, p.tile_rows, p.part_index, p.part_count);
+                    L.pixhash = mix32((L.x + L.y * p.width) + mix32(p.seed ^ 0x6A09E667U));
                     L.s = L.chunk * p.chunk_spp;
                     int e = L.s + p.chunk_spp;
                     L.s_end = e < p.spp ? e : p.spp;
@@ -254,10 +348,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
 
         // ---- start a new sample where the previous path ended ------------------------
         if (active && need_sample) {
-            uint32_t pix_full = L.x + L.y * p.width;
-            uint32_t h1 = mix32(p.seed ^ 0x6A09E667U);
-            uint32_t h2 = mix32(pix_full + h1);
-            L.rng.key = mix32(h2 ^ ((p.sample_base + (uint32_t)L.s) * 0x9E3779B9U));
+            L.rng.key = mix32(L.pixhash ^ ((p.sample_base + (uint32_t)L.s) * 0x9E3779B9U));
             L.rng.n = 0;
             camera_ray<MODE>(p, L);
             L.thr = v3(1.0f, 1.0f, 1.0f);
@@ -274,12 +365,10 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
             const float tmin = L.tmin;
 #if RT_STRICT
             const float a = dx * dx + dy * dy + dz * dz;
-#endif
 #pragma unroll 4
             for (int i = 0; i < p.n_pad; i++) {
                 const float4 g = s_geom[i];
                 const float ocx = g.x - ox, ocy = g.y - oy, ocz = g.z - oz;
-#if RT_STRICT
                 const float h = dx * ocx + dy * ocy + dz * ocz;
                 const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - g.w;
                 const float disc = h * h - a * c;
@@ -293,18 +382,62 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
                     }
                     if (ok) { closest = root; hit = i; }
                 }
+            }
 #else
+            // Big spheres first, exactly, for every lane.
+            for (int b = 0; b < p.nbig; b++) {
+                const int i = p.big[b];
+                const float4 g = s_geom[i];
+                const float ocx = g.x - ox, ocy = g.y - oy, ocz = g.z - oz;
                 const float h = fmaf(dz, ocz, fmaf(dy, ocy, dx * ocx));
                 const float negc = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, g.w)));
                 const float disc = fmaf(h, h, negc);
-                if (disc >= 0.0f) {
-                    const float sq = rt_sqrt(disc);
-                    const float t0 = h - sq;
-                    const float t = (t0 > tmin) ? t0 : (h + sq);
-                    if (t > tmin && t < closest) { closest = t; hit = i; }
-                }
-#endif
+                if (disc >= 0.0f) accept(h, disc, tmin, i, closest, hit);
             }
+            // Conservative filter over the rest, two spheres per packed instruction, sphere
+            // data from the scalar cache.  A pass only queues the index; the exact test runs
+            // after the scan (drain) with one candidate per lane per step.
+            const float oo = fmaf(oz, oz, fmaf(oy, oy, ox * ox));
+            const float reach = rt_sqrt(oo) + p.c_near;                       // >= |O| + |C|
+            const float slack = fmaf(reach * reach, 1.9073486e-6f, 1e-30f);   // 2^-19 (|O|+|C|)^2
+            const float base = slack - oo;
+            const float ndo = -fmaf(dz, oz, fmaf(dy, oy, dx * ox));
+            const float ox2 = ox + ox, oy2 = oy + oy, oz2 = oz + oz;
+            const_f8 *gp = (const_f8 *)p.pairs;
+            const int npairs = p.n_pad >> 1;
+            int cnt = 0;
+            for (int k0 = 0; k0 < npairs; k0 += kPairBatch) {
+#pragma unroll
+                for (int u = 0; u < kPairBatch; u++) {
+                    const f8 s = gp[k0 + u];
+                    const f2 cx = {s[0], s[1]}, cy = {s[2], s[3]}, cz = {s[4], s[5]};
+                    f2 h = __builtin_elementwise_fma(cx, (f2)dx, (f2)ndo);
+                    h = __builtin_elementwise_fma(cy, (f2)dy, h);
+                    h = __builtin_elementwise_fma(cz, (f2)dz, h);
+                    f2 m = __builtin_elementwise_fma(cx, (f2)ox2, (f2)base);
+                    m = __builtin_elementwise_fma(cy, (f2)oy2, m);
+                    m = __builtin_elementwise_fma(cz, (f2)oz2, m);
+                    const f2 e = __builtin_elementwise_fma(h, h, m);
+                    // m < k: the origin is outside the sphere; with h < 0 the sphere lies behind it
+                    // (the empty asm keeps the second test inside the rarely taken branch)
+                    if (e.x >= s[6]) {
+                        float hh = h.x, mm = m.x;
+                        asm volatile("" : "+v"(hh), "+v"(mm));
+                        if (!(hh < 0.0f && mm < s[6])) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u)); cnt++; }
+                    }
+                    if (e.y >= s[7]) {
+                        float hh = h.y, mm = m.y;
+                        asm volatile("" : "+v"(hh), "+v"(mm));
+                        if (!(hh < 0.0f && mm < s[7])) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u) + 1); cnt++; }
+                    }
+                }
+                if (__ballot(cnt > kQueueSlots - 2 * kPairBatch) != 0ULL) {
+                    drain(s_geom, queue, cnt, lane, ox, oy, oz, dx, dy, dz, tmin, closest, hit);
+                    cnt = 0;
+                }
+            }
+            drain(s_geom, queue, cnt, lane, ox, oy, oz, dx, dy, dz, tmin, closest, hit);
+#endif
             if (L.zero_dir) hit = -1;
         }
 
@@ -314,6 +447,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
             if (p.hit_index != nullptr && L.bounce == 0 && L.s == p.spp - 1) p.hit_index[L.pixc] = hit;
             bool done = false;
             V3 add_col = v3(0.0f, 0.0f, 0.0f);
+#if RT_STRICT
             if (hit >= 0) {
                 const float4 g = s_geom[hit];
                 const float4 mA = s_matA[hit];
@@ -349,6 +483,48 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
                 set_ray<MODE>(L, P, nd);
                 L.bounce++;
                 if (L.bounce >= p.max_depth) done = true;                   // Main.c:761: black
+#else
+            if (hit >= 0) {
+                // Same scatter rules (Main.c:558-620) for a unit-length incoming direction, with
+                // the three materials evaluated side by side and selected, so that a wave with
+                // mixed materials does not run three code paths one after another.
+                const float4 g = s_geom[hit];
+                const float4 mA = s_matA[hit];
+                const float4 mB = s_matB[hit];
+                const int mtype = __float_as_int(mB.y);
+                const V3 P = add(L.o, scale(L.d, closest));
+                const V3 outward = scale(sub(P, v3(g.x, g.y, g.z)), mB.z);
+                const float dn = dot(L.d, outward);
+                const bool front = dn < 0.0f;
+                const V3 n = front ? outward : scale(outward, -1.0f);
+                const float cosi = fabsf(dn);                               // -dot(d, n)
+                const V3 refl = add(L.d, scale(n, 2.0f * cosi));            // vec3f_reflect(d, n)
+                V3 rnd = v3(0.0f, 0.0f, 0.0f);
+                float u = 0.0f;
+                if (mtype != 2) rnd = sphere_direction<MODE>(L.rng);
+                else u = rng_float<MODE>(L.rng);
+                // Lambertian
+                V3 nd_l = add(n, rnd);
+                const float eps = 1e-8f;
+                if (fabsf(nd_l.x) < eps && fabsf(nd_l.y) < eps && fabsf(nd_l.z) < eps) nd_l = n;
+                // Metal
+                const V3 nd_m = add(unit(refl), scale(rnd, mA.w));
+                // Dielectric
+                const float ri = front ? __builtin_amdgcn_rcpf(mB.x) : mB.x;
+                const float cos_theta = fminf(cosi, 1.0f);
+                const float sin_theta = rt_sqrt(fmaxf(0.0f, fmaf(-cos_theta, cos_theta, 1.0f)));
+                const bool reflects = (ri * sin_theta > 1.0f) || (reflectance(cos_theta, ri) > u);
+                const V3 perp = scale(add(L.d, scale(n, cos_theta)), ri);
+                const V3 par = scale(n, -rt_sqrt(fabsf(1.0f - lensq(perp))));
+                const V3 nd_d = reflects ? refl : add(perp, par);
+                V3 nd = (mtype == 0) ? nd_l : ((mtype == 1) ? nd_m : nd_d);
+                const bool attenuate = (mtype != 1) || (dot(nd_m, n) > 0.0f);
+                const V3 att = (mtype == 2) ? v3(1.0f, 1.0f, 1.0f) : v3(mA.x, mA.y, mA.z);
+                if (attenuate) L.thr = mul(L.thr, att);
+                set_ray<MODE>(L, P, nd);
+                L.bounce++;
+                if (L.bounce >= p.max_depth) done = true;
+#endif
             } else {                                                        // sky, Main.c:744-758
                 const V3 ud = unit(L.d);
                 const float t = 0.5f * (ud.y + 1.0f);

@@ -129,7 +129,9 @@ def test_fast_build_is_deterministic_and_statistically_equal_to_strict(rt):
     assert abs(a["accum"].mean() - s["accum"].mean()) < 2e-3 * s["accum"].mean()
     ra, rs = a["stats"].rays / a["stats"].samples, s["stats"].rays / s["stats"].samples
     assert abs(ra - rs) < 0.02
-    assert psnr(a["rgba"], s["rgba"]) > 30.0     # same samples, a few paths differ by rounding
+    # the fast build draws its scatter directions with a direct map instead of the rejection
+    # loop, so the two images are independent estimates: compare them as such
+    assert psnr(a["rgba"], s["rgba"]) > 24.0
 
 
 @pytest.mark.parametrize("scene,gold_spp,gpu_spp", [("s3", 4096, 4096), ("sf", 2048, 8192)])
