@@ -64,6 +64,16 @@ typedef struct rt_camera_params {
     float   focus_dist;
 } rt_camera_params;
 
+/* Random numbers.  The reference's thread-local LCG (fast_rand, src/util.c:27-39) is replaced by a
+ * counter-based generator so that an image does not depend on tiles, GPUs or scheduling:
+ *     mix32(x): x ^= x>>16; x *= 0x7feb352d; x ^= x>>15; x *= 0x846ca68b; x ^= x>>16
+ *     key    = mix32( mix32(pixel + mix32(seed ^ 0x6A09E667)) ^ (sample * 0x9E3779B9) )
+ *     draw_n = mix32(key + n * 0x9E3779B9),  n = 0,1,2,... within one sample
+ *     u      = (draw_n >> 8) * 2^-24                       (replaces RAND_FLOAT, include/util.h:93)
+ * pixel = x + y*width in the FULL image, sample = sample_base + index within the call.  In the
+ * strict build draws are consumed in the reference's order (jitter x, jitter y, defocus disk,
+ * then per bounce the scatter draws); the fast build uses the same generator with its own
+ * samplers. */
 enum {
     RT_MODE_MC      = 0,  /* Monte-Carlo: counter-based RNG keyed (seed, pixel, sample) */
     RT_MODE_CONST_U = 1   /* deterministic: every random draw returns 0.5, i.e. the
