@@ -418,17 +418,22 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
                     m = __builtin_elementwise_fma(cy, (f2)oy2, m);
                     m = __builtin_elementwise_fma(cz, (f2)oz2, m);
                     const f2 e = __builtin_elementwise_fma(h, h, m);
-                    // m < k: the origin is outside the sphere; with h < 0 the sphere lies behind it
-                    // (the empty asm keeps the second test inside the rarely taken branch)
-                    if (e.x >= s[6]) {
-                        float hh = h.x, mm = m.x;
-                        asm volatile("" : "+v"(hh), "+v"(mm));
-                        if (!(hh < 0.0f && mm < s[6])) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u)); cnt++; }
-                    }
-                    if (e.y >= s[7]) {
-                        float hh = h.y, mm = m.y;
-                        asm volatile("" : "+v"(hh), "+v"(mm));
-                        if (!(hh < 0.0f && mm < s[7])) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u) + 1); cnt++; }
+                    // One wave-uniform branch per pair keeps the common no-pass case at two
+                    // compares and one scalar branch.  Inside: m < k means the origin is outside
+                    // the sphere; with h < 0 the sphere then lies behind it and is not queued.
+                    // (The empty asm keeps that second test inside the rarely taken branch.)
+                    const bool px = e.x >= s[6], py = e.y >= s[7];
+                    if (__ballot(px || py) != 0ULL) {
+                        if (px) {
+                            float hh = h.x, mm = m.x;
+                            asm volatile("" : "+v"(hh), "+v"(mm));
+                            if (!(hh < 0.0f && mm < s[6])) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u)); cnt++; }
+                        }
+                        if (py) {
+                            float hh = h.y, mm = m.y;
+                            asm volatile("" : "+v"(hh), "+v"(mm));
+                            if (!(hh < 0.0f && mm < s[7])) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u) + 1); cnt++; }
+                        }
                     }
                 }
                 if (__ballot(cnt > kQueueSlots - 2 * kPairBatch) != 0ULL) {

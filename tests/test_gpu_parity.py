@@ -213,3 +213,83 @@ def test_full_size_properties(rt, scene, width, spp):
                   part_index=tiles // 2, part_count=tiles)
     rows = rt.part_row_map(H, 16, tiles // 2, tiles)
     assert np.array_equal(a["rgba"][rows], c["rgba"][rows])
+
+
+def _random_scene(kind, n, seed):
+    r = np.random.default_rng(seed)
+    s = np.zeros(n, dtype=rc.SPHERE_DTYPE)
+    if kind == "wide":          # large coordinates, one huge ground, several big spheres
+        s["center"] = r.uniform(-50, 50, (n, 3))
+        s["radius"] = r.uniform(0.5, 5.0, n)
+        s["center"][0] = (0, -5000, 0)
+        s["radius"][0] = 4950.0
+        s["center"][1] = (30, 10, -400)
+        s["radius"][1] = 300.0
+    elif kind == "tiny":        # small scene far from the origin of coordinates
+        s["center"] = r.uniform(-1, 1, (n, 3)) + np.array([200.0, 50.0, -120.0])
+        s["radius"] = r.uniform(0.05, 0.3, n)
+    else:                        # nested glass shells around the look-at point
+        s["center"] = r.normal(0, 0.05, (n, 3))
+        s["radius"] = np.linspace(0.2, 3.0, n)
+    s["mat_type"] = r.integers(0, 3, n)
+    if kind == "nested":
+        s["mat_type"] = 2
+    s["albedo"] = r.uniform(0.2, 0.9, (n, 3))
+    s["fuzz"] = r.uniform(0, 0.5, n)
+    s["ior"] = 1.5
+    return s
+
+
+@pytest.mark.parametrize("kind,n,pos,target", [
+    ("wide", 300, (120.0, 40.0, 90.0), (0.0, 0.0, 0.0)),
+    ("tiny", 200, (201.5, 50.5, -118.5), (200.0, 50.0, -120.0)),
+    ("nested", 40, (6.0, 2.0, 5.0), (0.0, 0.0, 0.0))])
+def test_fast_filter_never_loses_a_hit(rt, kind, n, pos, target):
+    """The fast build's packed filter is conservative by construction; check it on scenes that
+    stress its error bound (huge and tiny coordinates, origins inside many spheres): primary
+    hit indices against the strict build, and converged colour against the strict build."""
+    sph = _random_scene(kind, n, 5)
+    rt.set_world(sph)
+    p = rt.default_params()
+    p.pos = rt.Vec3(*pos)
+    p.target = rt.Vec3(*target)
+    p.defocus_angle = 0.0
+    p.vfov = 100.0               # the reference's tan_f32 quirk narrows this a lot
+    W, H = 320, 180
+    cam = rt.camera(W, H, p)
+    a = rt.render(cam, W, H, 1, 1, mode=rt.MODE_CONST_U, strict_fp=True, want_hit=True)
+    b = rt.render(cam, W, H, 1, 1, mode=rt.MODE_CONST_U, strict_fp=False, want_hit=True)
+    assert (a["hit"] >= 0).mean() > 0.05                     # the view does see the scene
+    assert (a["hit"] != b["hit"]).mean() < 2e-3              # silhouette pixels only
+    s = rt.render(cam, W, H, 256, 12, strict_fp=True, seed=1, chunk_spp=64, want_accum=True)
+    f = rt.render(cam, W, H, 256, 12, strict_fp=False, seed=2, chunk_spp=64, want_accum=True)
+    assert abs(f["accum"].mean() - s["accum"].mean()) < 0.01 * s["accum"].mean() + 1e-4
+    assert abs(f["stats"].rays / f["stats"].samples - s["stats"].rays / s["stats"].samples) < 0.05
+    assert psnr(f["rgba"], s["rgba"]) > 27.0                 # two independent 256-spp estimates
+
+
+def test_headless_c_host_writes_the_same_frame(rt, tmp_path):
+    """raytracer_amd/host/rt_main (plain C over the C ABI) against the Python mirror."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "raytracer_amd", "host", "rt_main")
+    _, W, H = load_camera_golden(400)
+    rt.set_world(load_scene("sf"))
+    ref = rt.render(rt.camera(W, H), W, H, 3, 20, seed=6, chunk_spp=2)["rgba"]
+    rt.shutdown()                                            # one owner of the device at a time
+    for ext in ("ppm", "tga"):
+        out = str(tmp_path / ("f." + ext))
+        subprocess.check_call([exe, "--scene", os.path.join(GOLD, "scene_sf.bin"), "--width", "400",
+                               "--spp", "3", "--depth", "20", "--seed", "6", "--chunk", "2", "--out", out])
+        raw = open(out, "rb").read()
+        if ext == "ppm":
+            head = b"P6\n%d %d\n255\n" % (W, H)
+            assert raw.startswith(head)
+            img = np.frombuffer(raw[len(head):], np.uint8).reshape(H, W, 3)
+            assert np.array_equal(img, ref[..., :3])
+        else:                                                # export_image layout, base_graphics.c:583-615
+            assert raw[2] == 2 and raw[16] == 32 and raw[17] & 0x20
+            assert raw[12] | (raw[13] << 8) == W and raw[14] | (raw[15] << 8) == H
+            img = np.frombuffer(raw[18:], np.uint8).reshape(H, W, 4)
+            assert np.array_equal(img[..., [2, 1, 0, 3]], ref)
+    rt.init(0)
