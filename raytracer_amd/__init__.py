@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librtmi.so")
+LIB_PATH = os.environ.get("RTMI_LIB", os.path.join(HERE, "librtmi.so"))   # RTMI_LIB: diagnostic builds
 CSRC = os.path.join(HERE, "csrc")
 
 MODE_MC, MODE_CONST_U = 0, 1

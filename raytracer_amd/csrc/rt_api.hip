@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -144,7 +145,7 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
             if (d_hit) HIP_TRY(hipMemsetAsync(d_hit, 0xff, (size_t)npix * 4, g.stream));
         } else {
             HIP_TRY(g.partial.reserve((size_t)units * sizeof(float4)));
-            HIP_TRY(hipMemsetAsync(g.counters.p, 0, 2 * sizeof(unsigned long long), g.stream));
+            HIP_TRY(hipMemsetAsync(g.counters.p, 0, 8 * sizeof(unsigned long long), g.stream));
 
             TraceParams tp;
             memset(&tp, 0, sizeof tp);
@@ -213,8 +214,11 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
     if (o.stats) {
         st.samples = (uint64_t)npix * (uint64_t)spp;
         if (npix > 0 && max_depth > 0) {
-            unsigned long long c[2] = {0, 0};
+            unsigned long long c[8] = {0};
             HIP_TRY(hipMemcpy(c, g.counters.p, sizeof c, hipMemcpyDeviceToHost));
+            if (getenv("RT_DEBUG_COUNTS"))      // meaningful only in a -DRT_PROFILE_COUNTS build
+                fprintf(stderr, "rt counts: lane-iterations %llu filter-passes %llu queued %llu flush-lanes %llu queued-at-drain %llu\n",
+                        c[6], c[2], c[3], c[4], c[5]);
             st.rays = c[1];
             st.sphere_tests = c[1] * (uint64_t)g.n;
             float ms = 0.0f;
@@ -253,7 +257,7 @@ int rt_init(int device)
     HIP_TRY(hipEventCreate(&g.ev0));
     HIP_TRY(hipEventCreate(&g.ev1));
     HIP_TRY(hipEventCreate(&g.ev2));
-    HIP_TRY(g.counters.reserve(2 * sizeof(unsigned long long)));
+    HIP_TRY(g.counters.reserve(8 * sizeof(unsigned long long)));
     g.inited = true;
     g_err[0] = 0;
     return RT_OK;

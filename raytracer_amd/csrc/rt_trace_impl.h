@@ -306,6 +306,13 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
     bool need_unit = true;     // lane must pull a new work unit
     bool need_sample = true;   // lane must start a new sample
     uint32_t rays = 0;
+#ifdef RT_PROFILE_COUNTS
+    // Diagnostic build only: per-lane event counts, summed into counters[2..5] at the end.
+    uint32_t c_events = 0, c_appends = 0, c_flushes = 0, c_drain_iters = 0, c_iters = 0;
+#define RT_COUNT(var, n) var += (uint32_t)(n)
+#else
+#define RT_COUNT(var, n) ((void)0)
+#endif
 
     for (;;) {
         // ---- pull work units: one atomic per wave ------------------------------------
@@ -356,6 +363,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
             need_sample = false;
         }
 
+        RT_COUNT(c_iters, 1);
         // ---- hit(): nearest sphere along the ray, Main.c:688-713 -----------------------
         float closest = 3.402823466e+38f;      // max_f32
         int hit = -1;
@@ -427,20 +435,25 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
                         if (px) {
                             float hh = h.x, mm = m.x;
                             asm volatile("" : "+v"(hh), "+v"(mm));
-                            if (!(hh < 0.0f && mm < s[6])) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u)); cnt++; }
+                            RT_COUNT(c_events, 1);
+                        if (!(hh < 0.0f && mm < s[6])) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u)); cnt++; RT_COUNT(c_appends, 1); }
                         }
                         if (py) {
                             float hh = h.y, mm = m.y;
                             asm volatile("" : "+v"(hh), "+v"(mm));
-                            if (!(hh < 0.0f && mm < s[7])) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u) + 1); cnt++; }
+                            RT_COUNT(c_events, 1);
+                        if (!(hh < 0.0f && mm < s[7])) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u) + 1); cnt++; RT_COUNT(c_appends, 1); }
                         }
                     }
                 }
                 if (__ballot(cnt > kQueueSlots - 2 * kPairBatch) != 0ULL) {
+                    RT_COUNT(c_flushes, 1);
+                    RT_COUNT(c_drain_iters, cnt);
                     drain(s_geom, queue, cnt, lane, ox, oy, oz, dx, dy, dz, tmin, closest, hit);
                     cnt = 0;
                 }
             }
+            RT_COUNT(c_drain_iters, cnt);
             drain(s_geom, queue, cnt, lane, ox, oy, oz, dx, dy, dz, tmin, closest, hit);
 #endif
             if (L.zero_dir) hit = -1;
@@ -554,6 +567,13 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
     unsigned long long r64 = rays;
     for (int off = 32; off > 0; off >>= 1) r64 += __shfl_down(r64, off);
     if (__lane_id() == 0) atomicAdd(&p.counters[1], r64);
+#ifdef RT_PROFILE_COUNTS
+    atomicAdd(&p.counters[2], (unsigned long long)c_events);
+    atomicAdd(&p.counters[3], (unsigned long long)c_appends);
+    atomicAdd(&p.counters[4], (unsigned long long)c_flushes);
+    atomicAdd(&p.counters[5], (unsigned long long)c_drain_iters);
+    atomicAdd(&p.counters[6], (unsigned long long)c_iters);
+#endif
 }
 
 }  // namespace RT_NS
