@@ -47,5 +47,24 @@ for variant in s3:0 sf:1; do
     gcc -Wl,--gc-sections "$OUT/harness_$name.o" "$OUT/util.o" "$OUT/base_graphics.o" "$OUT/arena.o" \
         -o "$OUT/ref_harness_$name" -lm -lpthread
 done
+# Drop-in demonstration: the reference's render_all_parallel with its tile/thread dispatch
+# (Main.c:1002-1054) replaced by rt_render(); needs raytracer_amd/librtmi.so.
+LIB="$HERE/../raytracer_amd"
+if [ -f "$LIB/librtmi.so" ]; then
+    sed -n '1002p' "$R/Main.c" | grep -q 'int num_threads = get_core_count()\*2;' || { echo "build_ref: Main.c:1002 anchor missing" >&2; exit 1; }
+    sed -n '1055p' "$R/Main.c" | grep -q '^\s*$' || { echo "build_ref: Main.c:1055 anchor missing" >&2; exit 1; }
+    for variant in s3:0 sf:1; do
+        name=${variant%%:*}; on=${variant##*:}
+        { echo '#define main ref_main'
+          cat "$HERE/ref_dropin_prelude.h"
+          sed -e "1226s/#if 0/#if $on/" -e '1002,1054c\    RT_DROPIN_CALL' "$R/Main.c"
+          echo '#undef main'
+          cat "$HERE/ref_dropin.c"; } \
+          | gcc "${CF[@]}" -I"$HERE/../include" -x c - -c -o "$OUT/dropin_$name.o"
+        gcc -Wl,--gc-sections "$OUT/dropin_$name.o" "$OUT/util.o" "$OUT/base_graphics.o" "$OUT/arena.o" \
+            -o "$OUT/ref_dropin_$name" -L"$LIB" -lrtmi -Wl,-rpath,'$ORIGIN/../../raytracer_amd' -lm -lpthread
+    done
+    echo "build_ref: built $OUT/ref_dropin_s3 $OUT/ref_dropin_sf"
+fi
 rm -f "$OUT"/*.o
 echo "build_ref: built $OUT/ref_harness_s3 $OUT/ref_harness_sf"

@@ -293,3 +293,30 @@ def test_headless_c_host_writes_the_same_frame(rt, tmp_path):
             img = np.frombuffer(raw[18:], np.uint8).reshape(H, W, 4)
             assert np.array_equal(img[..., [2, 1, 0, 3]], ref)
     rt.init(0)
+
+
+@pytest.mark.parametrize("scene", ["s3", "sf"])
+def test_reference_host_with_rt_render_dropped_in(rt, scene, tmp_path):
+    """oracle/_ref/ref_dropin_*: the reference's own render_all_parallel (arena framebuffer,
+    clear_screen, bitmap-font overlay) with its tile/thread dispatch (Main.c:1002-1054) replaced
+    by rt_render().  The frame must equal rt_render's output everywhere but under the overlay
+    text, and the overlay must have been drawn on the read-back buffer."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_dropin_" + scene)
+    if not os.path.exists(exe):
+        pytest.skip("compiled reference not present (oracle/build_ref.sh needs /root/reference)")
+    _, W, H = load_camera_golden(400)
+    rt.set_world(load_scene(scene))
+    ref = rt.render(rt.camera(W, H), W, H, 4, 20, strict_fp=True, seed=12, chunk_spp=2)["rgba"]
+    rt.shutdown()
+    out = str(tmp_path / "frame.rgba")
+    try:
+        subprocess.check_call([exe, "400", "4", "20", out, "1", "12", "2"])
+    finally:
+        rt.init(0)
+    img = np.fromfile(out, np.uint8).reshape(H, W, 4)
+    text = np.zeros((H, W), bool)
+    text[:18, W - 20 * 7 * 2:] = True        # 20 glyph cells of 7x9 px at scale 2 (Main.c:1056-1057)
+    assert np.array_equal(img[~text], ref[~text])
+    assert (img[text] != ref[text]).any() and (img[text][:, :3] == 255).all(axis=-1).any()
