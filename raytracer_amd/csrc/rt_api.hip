@@ -166,9 +166,7 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
             tp.counters = (unsigned long long *)g.counters.p;
             tp.total_units = units;
 
-            const size_t lds = o.strict_fp
-                ? ((size_t)g.n_pad + 2 * (size_t)g.n) * sizeof(float4)
-                : (size_t)g.n_pad * sizeof(float4) + (size_t)(kBlockThreads / 64) * kQueueSlots * 64 * sizeof(uint32_t);
+            const size_t lds = (o.strict_fp ? ((size_t)g.n_pad + 2 * (size_t)g.n) : (size_t)g.n_pad) * sizeof(float4) + kQueueLdsBytes;
             const int per_cu = o.strict_fp ? trace_blocks_per_cu_strict(lds) : trace_blocks_per_cu_fast(lds);
             uint64_t blocks = (uint64_t)g.num_cu * (uint64_t)per_cu;
             const uint64_t need = (units + kBlockThreads - 1) / kBlockThreads;
@@ -216,9 +214,6 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
         if (npix > 0 && max_depth > 0) {
             unsigned long long c[8] = {0};
             HIP_TRY(hipMemcpy(c, g.counters.p, sizeof c, hipMemcpyDeviceToHost));
-            if (getenv("RT_DEBUG_COUNTS"))      // meaningful only in a -DRT_PROFILE_COUNTS build
-                fprintf(stderr, "rt counts: lane-iterations %llu filter-passes %llu queued %llu flush-lanes %llu queued-at-drain %llu\n",
-                        c[6], c[2], c[3], c[4], c[5]);
             st.rays = c[1];
             st.sphere_tests = c[1] * (uint64_t)g.n;
             float ms = 0.0f;

@@ -22,9 +22,8 @@ constexpr int kGeomPad = 8;
 // test, in the reference's (C - O) form, runs on the queued spheres after the scan.  Spheres far
 // larger than the rest (the r = 1000 ground) would inflate that bound for every sphere, so they
 // are kept out of the filter (k = +inf) and tested exactly for every ray: big[] lists them.
-constexpr int kQueueSlots = 16;
 constexpr int kMaxBig = 16;
-constexpr int kPairBatch = 4;              // pairs per unrolled batch; kGeomPad == 2 * kPairBatch
+constexpr int kQueueLdsBytes = (512 / 64) * 16 * 64 * 4;   // per workgroup: 8 waves x 16 slots x 64 lanes x u32
 constexpr int kMaxSpheres = 2048;          // 48 B/sphere of LDS per workgroup (96 KB) + 32 KB of queues
 constexpr int kBlockThreads = 512;         // 8 waves per workgroup
 

@@ -165,6 +165,8 @@ __device__ __forceinline__ void disk_point(Rng &r, float &x, float &y)
     y = rad * __builtin_amdgcn_sinf(phi);
 }
 
+#endif   // !RT_STRICT
+
 // q = u / n, r = u % n for u < 2^32 without the 32-bit integer divide sequence: the f64
 // product is at most one below the quotient.
 __device__ __forceinline__ void divmod(uint32_t u, uint32_t n, double inv_n, uint32_t &q, uint32_t &r)
@@ -178,35 +180,125 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f8 __attribute__((ext_vector_type(8)));
 typedef const __attribute__((address_space(4))) f8 const_f8;      // scalar-cache loads
 
-// One candidate sphere against the lane's ray: the fast build's form of hit_sphere's
-// accept step (Main.c:659-671) for a unit-length direction (a == 1).
-__device__ __forceinline__ void accept(float h, float disc, float tmin, int i, float &closest, int &hit)
+// The ray a sphere is tested against, and the nearest hit found so far.  hit() keeps the first
+// of equal distances (strict '<' while scanning in index order, Main.c:699-704); candidates are
+// resolved out of order here, so the rule is written out: nearer wins, then the lower index.
+struct Probe {
+    float ox, oy, oz, dx, dy, dz, tmin;
+#if RT_STRICT
+    float a;            // |d|^2, Main.c:648
+#endif
+    float closest;
+    int hit;
+};
+
+// hit_sphere (Main.c:625-672) for sphere i, up to the accept decision.
+__device__ __forceinline__ void exact_test(const float4 *s_geom, int i, Probe &q)
 {
-    const float sq = rt_sqrt(disc);
-    const float t0 = h - sq;
-    const float t = (t0 > tmin) ? t0 : (h + sq);
-    if (t > tmin && t < closest) { closest = t; hit = i; }
+    const float4 g = s_geom[i];
+    const float ocx = g.x - q.ox, ocy = g.y - q.oy, ocz = g.z - q.oz;
+#if RT_STRICT
+    const float h = q.dx * ocx + q.dy * ocy + q.dz * ocz;
+    const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - g.w;
+    const float disc = h * h - q.a * c;
+    if (!(disc < 0.0f)) {
+        const float sq = rt_sqrt(disc);
+        float root = (h - sq) / q.a;
+        // Surrounds(root, tmin, closest) fails for the near root either because it is <= tmin,
+        // and then the far root is tried, or because it is >= closest, and then the far root,
+        // which is not smaller, fails too: the choice of root does not depend on closest.
+        if (!(q.tmin < root)) root = (h + sq) / q.a;
+        if (q.tmin < root && (root < q.closest || (root == q.closest && i < q.hit))) { q.closest = root; q.hit = i; }
+    }
+#else
+    const float h = fmaf(q.dz, ocz, fmaf(q.dy, ocy, q.dx * ocx));
+    const float negc = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, g.w)));
+    const float disc = fmaf(h, h, negc);
+    if (disc >= 0.0f) {
+        const float sq = rt_sqrt(disc);
+        const float t0 = h - sq;
+        const float t = (t0 > q.tmin) ? t0 : (h + sq);
+        if (t > q.tmin && (t < q.closest || (t == q.closest && i < q.hit))) { q.closest = t; q.hit = i; }
+    }
+#endif
 }
 
-// Resolve the queued candidates of every lane of the wave.  queue[j * 64 + lane] is the j-th
-// sphere index the lane queued.
-__device__ __forceinline__ void drain(const float4 *s_geom, const uint32_t *queue, int cnt, int lane,
-                                      float ox, float oy, float oz, float dx, float dy, float dz,
-                                      float tmin, float &closest, int &hit)
+constexpr int kQueueSlots = 16;            // per lane
+constexpr int kPairBatch = 4;              // pairs between two queue-overflow checks
+static_assert(kQueueLdsBytes == (kBlockThreads / 64) * kQueueSlots * 64 * 4, "host and kernel disagree on the queue size");
+static_assert(kGeomPad == 2 * kPairBatch, "the sphere list is padded to whole batches");
+
+// Exact test of the queued candidates of every lane of the wave; queue[j * 64 + lane] is the
+// j-th sphere index the lane queued (slot-major: a lane's LDS bank does not depend on j).
+__device__ __forceinline__ void drain(const float4 *s_geom, const uint32_t *queue, int cnt, int lane, Probe &q)
 {
-    for (int j = 0; __ballot(j < cnt) != 0ULL; j++) {
-        if (j < cnt) {
-            const int i = (int)queue[j * 64 + lane];
-            const float4 g = s_geom[i];
-            const float ocx = g.x - ox, ocy = g.y - oy, ocz = g.z - oz;
-            const float h = fmaf(dz, ocz, fmaf(dy, ocy, dx * ocx));
-            const float negc = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, g.w)));
-            const float disc = fmaf(h, h, negc);
-            if (disc >= 0.0f) accept(h, disc, tmin, i, closest, hit);
+    for (int j = 0; __ballot(j < cnt) != 0ULL; j++)
+        if (j < cnt) exact_test(s_geom, (int)queue[j * 64 + lane], q);
+}
+
+// hit() (Main.c:688-713) as filter + exact test.
+//
+// The filter is conservative and runs on two spheres per packed-FP32 instruction with the sphere
+// data in SGPRs (scalar-cache loads, wave-uniform index).  With a unit direction u the
+// discriminant is D = (u.C - u.O)^2 + 2 O.C - |O|^2 - (|C|^2 - r^2); the expanded form needs seven
+// packed FMAs per pair but cancels badly, so a sphere passes when D >= -slack, where slack bounds
+// the rounding error of the filter AND of the exact test it stands in front of (slack_scale *
+// (|O| + max|C|)^2): a sphere the exact test would accept is never dropped.  A pass only queues
+// the sphere's index; the exact test runs on the queue afterwards.  Spheres much larger than the
+// rest would inflate slack for everybody and are tested exactly for every ray instead (big[]).
+template <bool CULL_BEHIND>
+__device__ __forceinline__ void scan_spheres(const TraceParams &p, const float4 *s_geom, uint32_t *queue, int lane,
+                                             float ux, float uy, float uz, float slack_scale, Probe &q)
+{
+    for (int b = 0; b < p.nbig; b++) exact_test(s_geom, p.big[b], q);
+
+    const float ox = q.ox, oy = q.oy, oz = q.oz;
+    const float oo = fmaf(oz, oz, fmaf(oy, oy, ox * ox));
+    const float reach = __builtin_amdgcn_sqrtf(oo) * 1.0000005f + p.c_near;   // >= |O| + |C|
+    const float slack = fmaf(reach * reach, slack_scale, 1e-30f);
+    const float base = slack - oo;
+    const float ndo = -fmaf(uz, oz, fmaf(uy, oy, ux * ox));
+    const float ox2 = ox + ox, oy2 = oy + oy, oz2 = oz + oz;
+    const_f8 *gp = (const_f8 *)p.pairs;
+    const int npairs = p.n_pad >> 1;
+    int cnt = 0;
+    for (int k0 = 0; k0 < npairs; k0 += kPairBatch) {
+#pragma unroll
+        for (int u = 0; u < kPairBatch; u++) {
+            const f8 s = gp[k0 + u];
+            const f2 cx = {s[0], s[1]}, cy = {s[2], s[3]}, cz = {s[4], s[5]};
+            f2 h = __builtin_elementwise_fma(cx, (f2)ux, (f2)ndo);
+            h = __builtin_elementwise_fma(cy, (f2)uy, h);
+            h = __builtin_elementwise_fma(cz, (f2)uz, h);
+            f2 m = __builtin_elementwise_fma(cx, (f2)ox2, (f2)base);
+            m = __builtin_elementwise_fma(cy, (f2)oy2, m);
+            m = __builtin_elementwise_fma(cz, (f2)oz2, m);
+            const f2 e = __builtin_elementwise_fma(h, h, m);
+            const bool px = e.x >= s[6], py = e.y >= s[7];
+            // One wave-uniform branch per pair keeps the common no-pass case at two compares
+            // and one scalar branch.  Inside (fast build): m < k means the origin is outside
+            // the sphere; with h < 0 the sphere then lies behind it and is not queued.  (The
+            // empty asm keeps that second test inside the rarely taken branch.)
+            if (__ballot(px || py) != 0ULL) {
+                if (px) {
+                    float hh = h.x, mm = m.x;
+                    asm volatile("" : "+v"(hh), "+v"(mm));
+                    if (!CULL_BEHIND || !(hh < 0.0f && mm < s[6])) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u)); cnt++; }
+                }
+                if (py) {
+                    float hh = h.y, mm = m.y;
+                    asm volatile("" : "+v"(hh), "+v"(mm));
+                    if (!CULL_BEHIND || !(hh < 0.0f && mm < s[7])) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u) + 1); cnt++; }
+                }
+            }
+        }
+        if (__ballot(cnt > kQueueSlots - 2 * kPairBatch) != 0ULL) {
+            drain(s_geom, queue, cnt, lane, q);
+            cnt = 0;
         }
     }
+    drain(s_geom, queue, cnt, lane, q);
 }
-#endif
 
 struct Lane {
     // current ray (fast build: d is unit length and tmin carries the original length)
@@ -275,16 +367,17 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
     extern __shared__ float4 lds[];
     float4 *s_geom = lds;                    // [n_pad]
     for (int i = threadIdx.x; i < p.n_pad; i += blockDim.x) s_geom[i] = p.geom[i];
+    const int lane = (int)__lane_id();
 #if RT_STRICT
     float4 *s_matA = lds + p.n_pad;          // [n]
     float4 *s_matB = s_matA + p.n;           // [n]
     for (int i = threadIdx.x; i < p.n; i += blockDim.x) { s_matA[i] = p.matA[i]; s_matB[i] = p.matB[i]; }
+    uint32_t *queue = reinterpret_cast<uint32_t *>(s_matB + p.n) + (threadIdx.x >> 6) * (kQueueSlots * 64);
 #else
     // The fast build spends its LDS on the candidate queues (more resident waves); the material
     // records are read once per bounce, from global memory through the vector L1.
     const float4 *s_matA = p.matA;
     const float4 *s_matB = p.matB;
-    const int lane = (int)__lane_id();
     uint32_t *queue = reinterpret_cast<uint32_t *>(lds + p.n_pad) + (threadIdx.x >> 6) * (kQueueSlots * 64);
 #endif
     __syncthreads();
@@ -306,13 +399,6 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
     bool need_unit = true;     // lane must pull a new work unit
     bool need_sample = true;   // lane must start a new sample
     uint32_t rays = 0;
-#ifdef RT_PROFILE_COUNTS
-    // Diagnostic build only: per-lane event counts, summed into counters[2..5] at the end.
-    uint32_t c_events = 0, c_appends = 0, c_flushes = 0, c_drain_iters = 0, c_iters = 0;
-#define RT_COUNT(var, n) var += (uint32_t)(n)
-#else
-#define RT_COUNT(var, n) ((void)0)
-#endif
 
     for (;;) {
         // ---- pull work units: one atomic per wave ------------------------------------
@@ -362,102 +448,34 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
             L.bounce = 0;
             need_sample = false;
         }
-
-        RT_COUNT(c_iters, 1);
         // ---- hit(): nearest sphere along the ray, Main.c:688-713 -----------------------
-        float closest = 3.402823466e+38f;      // max_f32
-        int hit = -1;
-        {
-            const float ox = L.o.x, oy = L.o.y, oz = L.o.z;
-            const float dx = L.d.x, dy = L.d.y, dz = L.d.z;
-            const float tmin = L.tmin;
+        Probe q;
+        q.ox = L.o.x; q.oy = L.o.y; q.oz = L.o.z;
+        q.dx = L.d.x; q.dy = L.d.y; q.dz = L.d.z;
+        q.tmin = L.tmin;
+        q.closest = 3.402823466e+38f;          // max_f32, Main.c:734
+        q.hit = -1;
 #if RT_STRICT
-            const float a = dx * dx + dy * dy + dz * dz;
-#pragma unroll 4
-            for (int i = 0; i < p.n_pad; i++) {
-                const float4 g = s_geom[i];
-                const float ocx = g.x - ox, ocy = g.y - oy, ocz = g.z - oz;
-                const float h = dx * ocx + dy * ocy + dz * ocz;
-                const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - g.w;
-                const float disc = h * h - a * c;
-                if (!(disc < 0.0f)) {
-                    const float sq = rt_sqrt(disc);
-                    float root = (h - sq) / a;
-                    bool ok = (tmin < root) && (root < closest);
-                    if (!ok) {
-                        root = (h + sq) / a;
-                        ok = (tmin < root) && (root < closest);
-                    }
-                    if (ok) { closest = root; hit = i; }
-                }
+        {
+            // The filter needs a unit direction only to stay conservative, so hardware rsqrt
+            // is good enough; the exact test uses d as it is.  slack 2^-17 (|O|+|C|)^2 covers
+            // the filter's rounding, the rsqrt error and the rounding of the reference-order
+            // discriminant h*h - a*c that decides in exact_test.
+            q.a = q.dx * q.dx + q.dy * q.dy + q.dz * q.dz;
+            const float inv = (q.a > 0.0f) ? __builtin_amdgcn_rsqf(q.a) : 0.0f;
+            scan_spheres<false>(p, s_geom, queue, lane, q.dx * inv, q.dy * inv, q.dz * inv, 7.6293945e-6f, q);
+            if (!(q.a > 0.0f)) {
+                // a zero or NaN direction gives the filter nothing to work with: test everything
+                q.closest = 3.402823466e+38f; q.hit = -1;
+                for (int i = 0; i < p.n; i++) exact_test(s_geom, i, q);
             }
-#else
-            // Big spheres first, exactly, for every lane.
-            for (int b = 0; b < p.nbig; b++) {
-                const int i = p.big[b];
-                const float4 g = s_geom[i];
-                const float ocx = g.x - ox, ocy = g.y - oy, ocz = g.z - oz;
-                const float h = fmaf(dz, ocz, fmaf(dy, ocy, dx * ocx));
-                const float negc = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, g.w)));
-                const float disc = fmaf(h, h, negc);
-                if (disc >= 0.0f) accept(h, disc, tmin, i, closest, hit);
-            }
-            // Conservative filter over the rest, two spheres per packed instruction, sphere
-            // data from the scalar cache.  A pass only queues the index; the exact test runs
-            // after the scan (drain) with one candidate per lane per step.
-            const float oo = fmaf(oz, oz, fmaf(oy, oy, ox * ox));
-            const float reach = rt_sqrt(oo) + p.c_near;                       // >= |O| + |C|
-            const float slack = fmaf(reach * reach, 1.9073486e-6f, 1e-30f);   // 2^-19 (|O|+|C|)^2
-            const float base = slack - oo;
-            const float ndo = -fmaf(dz, oz, fmaf(dy, oy, dx * ox));
-            const float ox2 = ox + ox, oy2 = oy + oy, oz2 = oz + oz;
-            const_f8 *gp = (const_f8 *)p.pairs;
-            const int npairs = p.n_pad >> 1;
-            int cnt = 0;
-            for (int k0 = 0; k0 < npairs; k0 += kPairBatch) {
-#pragma unroll
-                for (int u = 0; u < kPairBatch; u++) {
-                    const f8 s = gp[k0 + u];
-                    const f2 cx = {s[0], s[1]}, cy = {s[2], s[3]}, cz = {s[4], s[5]};
-                    f2 h = __builtin_elementwise_fma(cx, (f2)dx, (f2)ndo);
-                    h = __builtin_elementwise_fma(cy, (f2)dy, h);
-                    h = __builtin_elementwise_fma(cz, (f2)dz, h);
-                    f2 m = __builtin_elementwise_fma(cx, (f2)ox2, (f2)base);
-                    m = __builtin_elementwise_fma(cy, (f2)oy2, m);
-                    m = __builtin_elementwise_fma(cz, (f2)oz2, m);
-                    const f2 e = __builtin_elementwise_fma(h, h, m);
-                    // One wave-uniform branch per pair keeps the common no-pass case at two
-                    // compares and one scalar branch.  Inside: m < k means the origin is outside
-                    // the sphere; with h < 0 the sphere then lies behind it and is not queued.
-                    // (The empty asm keeps that second test inside the rarely taken branch.)
-                    const bool px = e.x >= s[6], py = e.y >= s[7];
-                    if (__ballot(px || py) != 0ULL) {
-                        if (px) {
-                            float hh = h.x, mm = m.x;
-                            asm volatile("" : "+v"(hh), "+v"(mm));
-                            RT_COUNT(c_events, 1);
-                        if (!(hh < 0.0f && mm < s[6])) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u)); cnt++; RT_COUNT(c_appends, 1); }
-                        }
-                        if (py) {
-                            float hh = h.y, mm = m.y;
-                            asm volatile("" : "+v"(hh), "+v"(mm));
-                            RT_COUNT(c_events, 1);
-                        if (!(hh < 0.0f && mm < s[7])) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u) + 1); cnt++; RT_COUNT(c_appends, 1); }
-                        }
-                    }
-                }
-                if (__ballot(cnt > kQueueSlots - 2 * kPairBatch) != 0ULL) {
-                    RT_COUNT(c_flushes, 1);
-                    RT_COUNT(c_drain_iters, cnt);
-                    drain(s_geom, queue, cnt, lane, ox, oy, oz, dx, dy, dz, tmin, closest, hit);
-                    cnt = 0;
-                }
-            }
-            RT_COUNT(c_drain_iters, cnt);
-            drain(s_geom, queue, cnt, lane, ox, oy, oz, dx, dy, dz, tmin, closest, hit);
-#endif
-            if (L.zero_dir) hit = -1;
         }
+#else
+        scan_spheres<true>(p, s_geom, queue, lane, q.dx, q.dy, q.dz, 1.9073486e-6f, q);   // 2^-19
+        if (L.zero_dir) q.hit = -1;
+#endif
+        const float closest = q.closest;
+        const int hit = q.hit;
 
         // ---- shade: ray_color's loop body, Main.c:730-759 ------------------------------
         if (active) {
@@ -567,13 +585,6 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
     unsigned long long r64 = rays;
     for (int off = 32; off > 0; off >>= 1) r64 += __shfl_down(r64, off);
     if (__lane_id() == 0) atomicAdd(&p.counters[1], r64);
-#ifdef RT_PROFILE_COUNTS
-    atomicAdd(&p.counters[2], (unsigned long long)c_events);
-    atomicAdd(&p.counters[3], (unsigned long long)c_appends);
-    atomicAdd(&p.counters[4], (unsigned long long)c_flushes);
-    atomicAdd(&p.counters[5], (unsigned long long)c_drain_iters);
-    atomicAdd(&p.counters[6], (unsigned long long)c_iters);
-#endif
 }
 
 }  // namespace RT_NS
