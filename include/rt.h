@@ -145,6 +145,16 @@ int rt_render(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t heig
 int rt_render_device(const rt_camera *cam, uint8_t *rgba_dev, uint32_t width, uint32_t height,
                      int spp, int max_depth, const rt_opts *opts);
 
+/* Progressive display (no counterpart in the reference, which re-renders identical frames,
+ * Main.c:1440-1443): frame `frame_index` adds `spp` new samples per pixel (sample indices
+ * sample_base + frame_index*spp ...) to a per-pixel sum kept on the device and writes the
+ * image of ALL samples so far.  frame_index 0 starts a sequence; frames must follow in order
+ * with the same size, spp and partition.  After F frames the result equals, bit for bit in the
+ * strict build, one rt_render call with F*spp samples and the same chunk_spp (which must
+ * divide spp).  opts->accum_out receives the running mean. */
+int rt_render_progressive(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height,
+                          int spp, int max_depth, const rt_opts *opts, uint32_t frame_index);
+
 /* Number of image rows owned by part `part_index` of `part_count` (row tiles of
  * `tile_rows` rows dealt round-robin).  Pure host arithmetic. */
 uint32_t rt_part_rows(uint32_t height, int tile_rows, int part_index, int part_count);

@@ -46,6 +46,16 @@ def main():
     for s in ("s3", "sf"):
         run(s, "scene", 400, 1, 1).tofile(os.path.join(GOLD, "scene_%s.bin" % s))
 
+    # glass-heavy scene "SG" (BASELINE config 5): the reference holds no definition of it (only a
+    # screenshot), so it is DEFINED here: the final scene with every r = 0.2 sphere turned into
+    # glass (Dielectric, ior 1.5); viewed from pos (9, 7, 3) looking at the origin.
+    sf = np.fromfile(os.path.join(GOLD, "scene_sf.bin"), dtype=np.uint8).reshape(-1, 40).copy()
+    rec = sf.view("<f4").reshape(-1, 10)
+    small = rec[:, 3] == np.float32(0.2)
+    sf.view("<i4").reshape(-1, 10)[small, 4] = 2
+    rec[small, 9] = 1.5
+    sf.tofile(os.path.join(GOLD, "scene_sg.bin"))
+
     # cameras at the BASELINE widths (init_camera + update_camera_view, Main.c:839-928)
     cams = {}
     for w in (100, 400, 1200, 1920, 3840):

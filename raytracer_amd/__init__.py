@@ -56,7 +56,7 @@ SPHERE_DTYPE = np.dtype([("center", "<f4", 3), ("radius", "<f4"), ("mat_type", "
                          ("albedo", "<f4", 3), ("fuzz", "<f4"), ("ior", "<f4")])
 assert SPHERE_DTYPE.itemsize == 40
 
-EXPORTS = ["rt_init", "rt_set_world", "rt_render", "rt_render_device", "rt_part_rows",
+EXPORTS = ["rt_init", "rt_set_world", "rt_render", "rt_render_device", "rt_render_progressive", "rt_part_rows",
            "rt_part_row_at", "rt_camera_setup", "rt_camera_defaults", "rt_height_for",
            "rt_shutdown", "rt_last_error"]
 
@@ -86,6 +86,9 @@ def lib():
             f.restype = C.c_int
             f.argtypes = [C.POINTER(Camera), C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
                           C.POINTER(Opts)]
+        L.rt_render_progressive.restype = C.c_int
+        L.rt_render_progressive.argtypes = [C.POINTER(Camera), C.c_void_p, C.c_uint32, C.c_uint32, C.c_int,
+                                            C.c_int, C.POINTER(Opts), C.c_uint32]
         L.rt_part_rows.restype = C.c_uint32
         L.rt_part_rows.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int]
         L.rt_part_row_at.restype = C.c_uint32
@@ -178,6 +181,20 @@ def render(cam, width, height, spp, max_depth, mode=MODE_MC, strict_fp=False, se
     _check(lib().rt_render(C.byref(cam), rgba.ctypes.data, width, height, spp, max_depth, C.byref(o)),
            "rt_render")
     return dict(rgba=rgba, hit=hit, accum=acc, stats=st)
+
+
+def render_progressive(cam, width, height, spp, max_depth, frame_index, mode=MODE_MC, strict_fp=False,
+                       seed=0, sample_base=0, chunk_spp=0, want_accum=False, out=None):
+    """rt_render_progressive: adds one frame of `spp` samples; returns the image of all frames so far."""
+    rgba = out if out is not None else np.zeros((height, width, 4), dtype=np.uint8)
+    acc = np.zeros((height, width, 3), dtype=np.float32) if want_accum else None
+    st = Stats()
+    o = _opts(mode, strict_fp, seed, sample_base, chunk_spp, 0, 0, 0)
+    o.accum_out = acc.ctypes.data if want_accum else None
+    o.stats = C.addressof(st)
+    _check(lib().rt_render_progressive(C.byref(cam), rgba.ctypes.data, width, height, spp, max_depth,
+                                       C.byref(o), frame_index), "rt_render_progressive")
+    return dict(rgba=rgba, accum=acc, stats=st)
 
 
 def render_device(cam, rgba_dev_ptr, width, height, spp, max_depth, mode=MODE_MC, strict_fp=False,

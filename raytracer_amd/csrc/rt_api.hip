@@ -48,6 +48,10 @@ struct State {
     DevBuf geom, matA, matB, pairs;
     // scratch
     DevBuf partial, counters, rgba, accum, hit;
+    // progressive accumulation (rt_render_progressive): running per-pixel sums and what they belong to
+    DevBuf running;
+    uint32_t prog_w = 0, prog_h = 0, prog_npix = 0, prog_frames = 0;
+    int prog_spp = 0;
     std::vector<uint8_t> h_rgba;
     std::vector<float> h_accum;
     std::vector<int32_t> h_hit;
@@ -93,7 +97,7 @@ inline float turns_to_rad(float v) { return v * (2 * 3.1415926535897f); }
 inline float deg_to_rad(float v) { return turns_to_rad(v / 360.f); }
 
 int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height, int spp,
-                  int max_depth, const rt_opts *opts, bool device_ptrs)
+                  int max_depth, const rt_opts *opts, bool device_ptrs, int64_t frame_index = -1)
 {
     using clk = std::chrono::steady_clock;
     const auto t_start = clk::now();
@@ -123,6 +127,25 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
     const int nchunks = (spp + chunk - 1) / chunk;
     const uint64_t units = (uint64_t)npix * (uint64_t)nchunks;
     if (units >= 0xffffffffULL) return fail(RT_ERR_ARG, "rt_render: %llu work units; raise chunk_spp", (unsigned long long)units);
+
+    const bool progressive = frame_index >= 0;
+    uint32_t sample_base = o.sample_base;
+    if (progressive) {
+        if (max_depth < 1) return fail(RT_ERR_ARG, "rt_render_progressive: max_depth must be >= 1");
+        if (spp % chunk != 0) return fail(RT_ERR_ARG, "rt_render_progressive: chunk_spp (%d) must divide spp (%d)", chunk, spp);
+        if ((uint64_t)spp * (uint64_t)(frame_index + 1) > 0x7fffffffULL) return fail(RT_ERR_ARG, "rt_render_progressive: too many samples");
+        if (frame_index == 0) {
+            HIP_TRY(g.running.reserve((size_t)npix * sizeof(float4) + 16));
+            HIP_TRY(hipMemsetAsync(g.running.p, 0, (size_t)npix * sizeof(float4), g.stream));
+            g.prog_w = width; g.prog_h = height; g.prog_npix = npix; g.prog_spp = spp; g.prog_frames = 0;
+        }
+        if (g.prog_w != width || g.prog_h != height || g.prog_npix != npix || g.prog_spp != spp ||
+            (int64_t)g.prog_frames != frame_index)
+            return fail(RT_ERR_STATE, "rt_render_progressive: frame %lld does not continue the sequence "
+                        "(%u frames of %ux%u at %d spp accumulated); start again with frame_index 0",
+                        (long long)frame_index, g.prog_frames, g.prog_w, g.prog_h, g.prog_spp);
+        sample_base += (uint32_t)frame_index * (uint32_t)spp;
+    }
 
     rt_stats st;
     memset(&st, 0, sizeof st);
@@ -160,7 +183,7 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
             tp.width = width; tp.height = height; tp.npix = npix;
             tp.tile_rows = tile_rows; tp.part_index = part_index; tp.part_count = part_count;
             tp.spp = spp; tp.chunk_spp = chunk; tp.nchunks = nchunks; tp.max_depth = max_depth;
-            tp.mode = o.mode; tp.seed = o.seed; tp.sample_base = o.sample_base;
+            tp.mode = o.mode; tp.seed = o.seed; tp.sample_base = sample_base;
             tp.partial = (float4 *)g.partial.p;
             tp.hit_index = d_hit;
             tp.counters = (unsigned long long *)g.counters.p;
@@ -178,7 +201,8 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
             HIP_TRY(hipEventRecord(g.ev1, g.stream));
             ResolveParams rp;
             rp.partial = (const float4 *)g.partial.p; rp.nchunks = nchunks; rp.npix = npix;
-            rp.inv_spp = (float)1.0f / (float)spp;
+            rp.running = progressive ? (float4 *)g.running.p : nullptr;
+            rp.inv_spp = (float)1.0f / (float)(progressive ? spp * (int)(frame_index + 1) : spp);
             rp.rgba = d_rgba; rp.accum = d_accum;
             HIP_TRY(launch_resolve(rp, g.stream));
             HIP_TRY(hipEventRecord(g.ev2, g.stream));
@@ -208,6 +232,8 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
             if (o.hit_index_out) memcpy(o.hit_index_out + (size_t)y * width, g.h_hit.data() + (size_t)k * width, (size_t)width * 4);
         }
     }
+
+    if (progressive) g.prog_frames++;
 
     if (o.stats) {
         st.samples = (uint64_t)npix * (uint64_t)spp;
@@ -345,6 +371,12 @@ int rt_render_device(const rt_camera *cam, uint8_t *rgba_dev, uint32_t width, ui
     return render_common(cam, rgba_dev, width, height, spp, max_depth, opts, true);
 }
 
+int rt_render_progressive(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height, int spp,
+                          int max_depth, const rt_opts *opts, uint32_t frame_index)
+{
+    return render_common(cam, rgba, width, height, spp, max_depth, opts, false, (int64_t)frame_index);
+}
+
 uint32_t rt_part_rows(uint32_t height, int tile_rows, int part_index, int part_count)
 {
     if (part_count <= 1) return height;
@@ -415,12 +447,14 @@ void rt_shutdown(void)
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     g.geom.release(); g.matA.release(); g.matB.release(); g.pairs.release();
-    g.partial.release(); g.counters.release(); g.rgba.release(); g.accum.release(); g.hit.release();
+    g.partial.release(); g.running.release(); g.counters.release(); g.rgba.release(); g.accum.release(); g.hit.release();
     if (g.ev0) (void)hipEventDestroy(g.ev0);
     if (g.ev1) (void)hipEventDestroy(g.ev1);
     if (g.ev2) (void)hipEventDestroy(g.ev2);
     if (g.stream) (void)hipStreamDestroy(g.stream);
     g = State();
+    trace_forget_strict();
+    trace_forget_fast();
 }
 
 }  // extern "C"

@@ -58,7 +58,8 @@ struct ResolveParams {
     const float4 *partial;
     int nchunks;
     uint32_t npix;
-    float inv_spp;                         // (f32)1.0f/(f32)spp, Main.c:977
+    float4 *running;                       // progressive frames: per-pixel sum carried between calls, or nullptr
+    float inv_spp;                         // (f32)1.0f/(f32)spp, Main.c:977 (spp = all samples summed so far)
     uint8_t *rgba;                         // compact [npix][4]
     float *accum;                          // compact [npix][3] or nullptr
 };
@@ -77,5 +78,7 @@ hipError_t launch_trace_fast(const TraceParams &p, int blocks, size_t lds_bytes,
 hipError_t launch_resolve(const ResolveParams &p, hipStream_t s);
 int trace_blocks_per_cu_strict(size_t lds_bytes);
 int trace_blocks_per_cu_fast(size_t lds_bytes);
+void trace_forget_strict();   // rt_shutdown / device change: drop the cached launch set-up
+void trace_forget_fast();
 
 }  // namespace rtmi

@@ -320,3 +320,25 @@ def test_reference_host_with_rt_render_dropped_in(rt, scene, tmp_path):
     text[:18, W - 20 * 7 * 2:] = True        # 20 glyph cells of 7x9 px at scale 2 (Main.c:1056-1057)
     assert np.array_equal(img[~text], ref[~text])
     assert (img[text] != ref[text]).any() and (img[text][:, :3] == 255).all(axis=-1).any()
+
+
+def test_progressive_frames_equal_one_long_render(rt):
+    """rt_render_progressive: after F frames of s samples the device-side running sum gives,
+    bit for bit in the strict build, the image of one F*s-sample render chunked by s."""
+    _, W, H = load_camera_golden(100)
+    sph = load_scene("sg")
+    rt.set_world(sph)
+    cam = rt.camera(W, H)
+    for f in range(4):
+        prog = rt.render_progressive(cam, W, H, 2, 20, f, strict_fp=True, seed=3, want_accum=True)
+        one = rt.render(cam, W, H, 2 * (f + 1), 20, strict_fp=True, seed=3, chunk_spp=2, want_accum=True)
+        assert np.array_equal(bits(prog["accum"]), bits(one["accum"]))
+        assert np.array_equal(prog["rgba"], one["rgba"])
+    c = rc.render(rc.camera(W, H), sph, W, H, 8, 20, rng=rc.RNG_COUNTER, seed=3, chunk_spp=2, want_accum=True)
+    assert np.array_equal(bits(prog["accum"]), bits(c["accum"]))
+    with pytest.raises(rt.RtError, match="continue"):
+        rt.render_progressive(cam, W, H, 2, 20, 7, strict_fp=True, seed=3)      # skipped frames
+    with pytest.raises(rt.RtError, match="continue"):
+        rt.render_progressive(cam, W, H, 3, 20, 4, strict_fp=True, seed=3)      # changed spp
+    fast = [rt.render_progressive(cam, W, H, 1, 20, f, seed=3)["rgba"] for f in range(3)]
+    assert np.array_equal(fast[2], rt.render(cam, W, H, 3, 20, seed=3, chunk_spp=1)["rgba"])
