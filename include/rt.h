@@ -171,6 +171,18 @@ int rt_camera_setup(const rt_camera_params *p, uint32_t width, uint32_t height, 
 void rt_camera_defaults(rt_camera_params *p);
 uint32_t rt_height_for(uint32_t width, float aspect_ratio);
 
+/* init_scene (Main.c:1212-1318) restated on the host with a FIXED evaluation order.  The reference
+ * draws its RAND_FLOAT() values inside initialiser lists and argument lists (Main.c:1231-1256),
+ * whose order C leaves to the compiler; here it is: material choice, centre x, centre z, then the
+ * material's own draws in reading order.  Output: the ground sphere, one r = 0.2 sphere per cell
+ * (a, b) of [-half_extent, half_extent)^2 that is farther than 0.9 from (4, 0.2, 0), then the
+ * three unit spheres.  half_extent = 11 with lcg_seed = 0 reproduces, byte for byte, the scene
+ * the reference generates when built with gcc (its random block enabled); half_extent = 0 is
+ * the shipped three-sphere scene.  The generator is the reference's LCG (src/util.c:27-39).
+ * Writes at most `cap` records and the number of objects to *count; RT_ERR_ARG if cap is too
+ * small.  Pure host code. */
+int rt_scene_generate(int half_extent, uint32_t lcg_seed, rt_sphere *out, size_t cap, size_t *count);
+
 /* Frees everything rt_init / rt_set_world created. */
 void rt_shutdown(void);
 

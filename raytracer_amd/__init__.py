@@ -58,7 +58,7 @@ assert SPHERE_DTYPE.itemsize == 40
 
 EXPORTS = ["rt_init", "rt_set_world", "rt_render", "rt_render_device", "rt_render_progressive", "rt_part_rows",
            "rt_part_row_at", "rt_camera_setup", "rt_camera_defaults", "rt_height_for",
-           "rt_shutdown", "rt_last_error"]
+           "rt_scene_generate", "rt_shutdown", "rt_last_error"]
 
 _lib = None
 
@@ -99,6 +99,8 @@ def lib():
         L.rt_camera_defaults.argtypes = [C.POINTER(CameraParams)]
         L.rt_height_for.restype = C.c_uint32
         L.rt_height_for.argtypes = [C.c_uint32, C.c_float]
+        L.rt_scene_generate.restype = C.c_int
+        L.rt_scene_generate.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.rt_shutdown.restype = None
         L.rt_last_error.restype = C.c_char_p
         _lib = L
@@ -121,6 +123,15 @@ def shutdown():
 def set_world(spheres):
     spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
     _check(lib().rt_set_world(spheres.ctypes.data, len(spheres)), "rt_set_world")
+
+
+def scene_generate(half_extent=11, lcg_seed=0):
+    """rt_scene_generate: init_scene (Main.c:1212-1318) with a fixed evaluation order."""
+    cap = 4 * half_extent * half_extent + 4
+    out = np.zeros(cap, dtype=SPHERE_DTYPE)
+    n = C.c_size_t(0)
+    _check(lib().rt_scene_generate(half_extent, lcg_seed, out.ctypes.data, cap, C.byref(n)), "rt_scene_generate")
+    return out[:n.value].copy()
 
 
 def default_params():

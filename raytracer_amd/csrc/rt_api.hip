@@ -441,6 +441,54 @@ int rt_camera_setup(const rt_camera_params *p, uint32_t width, uint32_t height, 
     return RT_OK;
 }
 
+int rt_scene_generate(int half_extent, uint32_t lcg_seed, rt_sphere *out, size_t cap, size_t *count)
+{
+    if (half_extent < 0 || half_extent > 1000 || (!out && cap) || !count) return fail(RT_ERR_ARG, "rt_scene_generate: bad argument");
+    uint32_t state = lcg_seed;
+    auto rnd = [&state]() -> float {                                   // RAND_FLOAT, util.h:93; fast_rand, util.c:35-39
+        state = 214013u * state + 2531011u;
+        return (float)(int)((state >> 16) & 0x7FFF) / ((float)32767 + 1.0f);
+    };
+    size_t n = 0;
+    bool overflow = false;
+    auto push = [&](const rt_sphere &s) { if (n < cap) out[n] = s; else overflow = true; n++; };
+    auto sphere = [](float x, float y, float z, float r, int32_t type, float ar, float ag, float ab, float fuzz, float ior) {
+        rt_sphere s;
+        s.center = rt_vec3{x, y, z}; s.radius = r; s.mat_type = type; s.albedo = rt_vec3{ar, ag, ab};
+        s.fuzz = fuzz; s.refraction_index = ior;
+        return s;
+    };
+    push(sphere(0.0f, -1000.0f, 0.0f, 1000.0f, RT_MAT_LAMBERTIAN, 0.5f, 0.5f, 0.5f, 0.0f, 0.0f));      // Main.c:1216-1224
+    for (int a = -half_extent; a < half_extent; a++) {                                                 // Main.c:1229-1285
+        for (int b = -half_extent; b < half_extent; b++) {
+            const float choose_mat = rnd();
+            const float cx = a + 0.9f * rnd();
+            const float cz = b + 0.9f * rnd();
+            const float dx = cx - 4.0f, dy = 0.2f - 0.2f, dz = cz - 0.0f;
+            if (!(sqrtf(dx * dx + dy * dy + dz * dz) > 0.9f)) continue;
+            if (choose_mat < 0.8f) {
+                const float a0 = rnd(), a1 = rnd(), a2 = rnd();
+                const float b0 = rnd(), b1 = rnd(), b2 = rnd();
+                push(sphere(cx, 0.2f, cz, 0.2f, RT_MAT_LAMBERTIAN, a0 * b0, a1 * b1, a2 * b2, 0.0f, 0.0f));
+            } else if (choose_mat < 0.95f) {
+                const float r0 = 0.5f + (1.0f - 0.5f) * rnd();                                         // RAND_FLOAT_RANGE, util.h:94
+                const float r1 = 0.5f + (1.0f - 0.5f) * rnd();
+                const float r2 = 0.5f + (1.0f - 0.5f) * rnd();
+                const float fuzz = 0.0f + (0.5f - 0.0f) * rnd();
+                push(sphere(cx, 0.2f, cz, 0.2f, RT_MAT_METAL, r0, r1, r2, fuzz, 0.0f));
+            } else {
+                push(sphere(cx, 0.2f, cz, 0.2f, RT_MAT_DIELECTRIC, 0.0f, 0.0f, 0.0f, 0.0f, 1.5f));
+            }
+        }
+    }
+    push(sphere(0.0f, 1.0f, 0.0f, 1.0f, RT_MAT_DIELECTRIC, 0.0f, 0.0f, 0.0f, 0.0f, 1.5f));             // Main.c:1288-1296
+    push(sphere(-4.0f, 1.0f, 0.0f, 1.0f, RT_MAT_LAMBERTIAN, 0.4f, 0.2f, 0.1f, 0.0f, 0.0f));            // Main.c:1298-1306
+    push(sphere(4.0f, 1.0f, 0.0f, 1.0f, RT_MAT_METAL, 0.7f, 0.6f, 0.5f, 0.0f, 0.0f));                  // Main.c:1308-1317
+    *count = n;
+    if (overflow) return fail(RT_ERR_ARG, "rt_scene_generate: %zu objects do not fit %zu records", n, cap);
+    return RT_OK;
+}
+
 void rt_shutdown(void)
 {
     if (!g.inited) return;

@@ -4,9 +4,11 @@
  * (Main.c:1364-1410, 1440-1443): derive the camera, hand over the scene, call the renderer into
  * a caller-owned RGBA8 buffer, then write the buffer out.
  *
- *   rt_main --scene spheres.bin [--width 400] [--spp 10] [--depth 20] [--out frame.ppm|.tga]
+ *   rt_main (--scene spheres.bin | --generate HALF) [--width 400] [--spp 10] [--depth 20] [--out frame.ppm|.tga]
  *           [--strict] [--const-u] [--seed N] [--chunk N] [--device N] [--frames N]
  *
+ * --generate HALF builds the scene with rt_scene_generate (init_scene with its random block over
+ * [-HALF, HALF)^2; 11 = the reference's final scene, 0 = its shipped three-sphere scene).
  * spheres.bin: raw rt_sphere records (40 B each: center[3], radius, mat_type, albedo[3], fuzz,
  * refraction_index -- the reference's sphere_t, Main.c:74-79).
  * .tga output has the layout of the reference's export_image (src/base_graphics.c:583-615):
@@ -51,7 +53,7 @@ int main(int argc, char **argv)
 {
     const char *scene = NULL, *out = NULL;
     uint32_t width = 400;
-    int spp = 10, depth = 20, device = 0, frames = 1;      /* init_camera's defaults, Main.c:926-927 */
+    int spp = 10, depth = 20, device = 0, frames = 1, generate = -1;      /* init_camera's defaults, Main.c:926-927 */
     rt_opts o;
     rt_stats st;
     memset(&o, 0, sizeof o);
@@ -64,6 +66,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--const-u")) o.mode = RT_MODE_CONST_U;
         else if (!v) { fprintf(stderr, "rt_main: %s needs a value\n", a); return 2; }
         else if (!strcmp(a, "--scene")) { scene = v; i++; }
+        else if (!strcmp(a, "--generate")) { generate = atoi(v); i++; }
         else if (!strcmp(a, "--out")) { out = v; i++; }
         else if (!strcmp(a, "--width")) { width = (uint32_t)atoi(v); i++; }
         else if (!strcmp(a, "--spp")) { spp = atoi(v); i++; }
@@ -74,18 +77,26 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--frames")) { frames = atoi(v); i++; }
         else { fprintf(stderr, "rt_main: unknown option %s\n", a); return 2; }
     }
-    if (!scene) { fprintf(stderr, "usage: rt_main --scene spheres.bin [--width W] [--spp N] [--depth D] [--out f.ppm|f.tga]\n"); return 2; }
+    if (!scene && generate < 0) { fprintf(stderr, "usage: rt_main (--scene spheres.bin | --generate HALF) [--width W] [--spp N] [--depth D] [--out f.ppm|f.tga]\n"); return 2; }
 
-    FILE *f = fopen(scene, "rb");
-    if (!f) { perror(scene); return 1; }
-    fseek(f, 0, SEEK_END);
-    long bytes = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    if (bytes < 0 || bytes % (long)sizeof(rt_sphere) != 0) { fprintf(stderr, "rt_main: %s is not a whole number of 40-byte spheres\n", scene); return 1; }
-    size_t n = (size_t)bytes / sizeof(rt_sphere);
-    rt_sphere *spheres = (rt_sphere *)malloc(bytes > 0 ? (size_t)bytes : 1);
-    if (!spheres || fread(spheres, sizeof(rt_sphere), n, f) != n) { fprintf(stderr, "rt_main: cannot read %s\n", scene); return 1; }
-    fclose(f);
+    size_t n = 0;
+    rt_sphere *spheres = NULL;
+    if (scene) {
+        FILE *f = fopen(scene, "rb");
+        if (!f) { perror(scene); return 1; }
+        fseek(f, 0, SEEK_END);
+        long bytes = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        if (bytes < 0 || bytes % (long)sizeof(rt_sphere) != 0) { fprintf(stderr, "rt_main: %s is not a whole number of 40-byte spheres\n", scene); return 1; }
+        n = (size_t)bytes / sizeof(rt_sphere);
+        spheres = (rt_sphere *)malloc(bytes > 0 ? (size_t)bytes : 1);
+        if (!spheres || fread(spheres, sizeof(rt_sphere), n, f) != n) { fprintf(stderr, "rt_main: cannot read %s\n", scene); return 1; }
+        fclose(f);
+    } else {
+        size_t cap = 4 * (size_t)generate * (size_t)generate + 4;
+        spheres = (rt_sphere *)malloc(cap * sizeof(rt_sphere));
+        if (!spheres || rt_scene_generate(generate, 0, spheres, cap, &n)) { fprintf(stderr, "rt_main: %s\n", rt_last_error()); return 1; }
+    }
 
     uint32_t height = rt_height_for(width, 16.0f / 9.0f);             /* init_all, Main.c:1366-1369 */
     rt_camera_params cp;

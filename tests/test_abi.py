@@ -60,3 +60,19 @@ def test_render_before_init_is_an_error_not_a_crash():
         rt.render(cam, 100, 56, 1, 1, out=buf)
     with pytest.raises(rt.RtError, match="rt_init"):
         rt.set_world(np.zeros(1, rt.SPHERE_DTYPE))
+
+
+def test_scene_generator_reproduces_the_reference_scenes():
+    """rt_scene_generate against the sphere lists the compiled reference produced."""
+    import conftest
+    gold_sf = np.fromfile(os.path.join(conftest.GOLD, "scene_sf.bin"), dtype=rt.SPHERE_DTYPE)
+    gold_s3 = np.fromfile(os.path.join(conftest.GOLD, "scene_s3.bin"), dtype=rt.SPHERE_DTYPE)
+    assert rt.scene_generate(11, 0).tobytes() == gold_sf.tobytes()
+    assert rt.scene_generate(0, 0).tobytes() == gold_s3.tobytes()
+    other = rt.scene_generate(11, 1)
+    assert len(other) > 400 and other.tobytes() != gold_sf.tobytes()
+    big = rt.scene_generate(20, 0)
+    assert 1500 < len(big) <= 1604 and np.all(big["radius"][1:-3] == np.float32(0.2))
+    n = C.c_size_t(0)
+    buf = np.zeros(10, dtype=rt.SPHERE_DTYPE)
+    assert rt.lib().rt_scene_generate(11, 0, buf.ctypes.data, 10, C.byref(n)) == -1 and n.value == 488
