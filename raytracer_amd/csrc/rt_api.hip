@@ -189,15 +189,16 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
             tp.counters = (unsigned long long *)g.counters.p;
             tp.total_units = units;
 
-            const size_t lds = (o.strict_fp ? ((size_t)g.n_pad + 2 * (size_t)g.n) : (size_t)g.n_pad) * sizeof(float4) + kQueueLdsBytes;
-            const int per_cu = o.strict_fp ? trace_blocks_per_cu_strict(lds) : trace_blocks_per_cu_fast(lds);
+            const bool geom_global = g.n > kMaxSpheresLds;
+            const size_t lds = (geom_global ? 0 : (o.strict_fp ? ((size_t)g.n_pad + 2 * (size_t)g.n) : (size_t)g.n_pad) * sizeof(float4)) + kQueueLdsBytes;
+            const int per_cu = o.strict_fp ? trace_blocks_per_cu_strict(geom_global, lds) : trace_blocks_per_cu_fast(geom_global, lds);
             uint64_t blocks = (uint64_t)g.num_cu * (uint64_t)per_cu;
             const uint64_t need = (units + kBlockThreads - 1) / kBlockThreads;
             if (blocks > need) blocks = need;
 
             HIP_TRY(hipEventRecord(g.ev0, g.stream));
-            HIP_TRY(o.strict_fp ? launch_trace_strict(tp, (int)blocks, lds, g.stream)
-                                : launch_trace_fast(tp, (int)blocks, lds, g.stream));
+            HIP_TRY(o.strict_fp ? launch_trace_strict(tp, geom_global, (int)blocks, lds, g.stream)
+                                : launch_trace_fast(tp, geom_global, (int)blocks, lds, g.stream));
             HIP_TRY(hipEventRecord(g.ev1, g.stream));
             ResolveParams rp;
             rp.partial = (const float4 *)g.partial.p; rp.nchunks = nchunks; rp.npix = npix;
@@ -289,7 +290,7 @@ int rt_set_world(const rt_sphere *spheres, size_t count)
     if (!g.inited) return fail(RT_ERR_STATE, "rt_set_world: rt_init has not been called");
     if (!spheres && count) return fail(RT_ERR_ARG, "rt_set_world: null sphere array");
     if (count > (size_t)kMaxSpheres)
-        return fail(RT_ERR_ARG, "rt_set_world: %zu spheres; at most %d fit the per-workgroup LDS image", count, kMaxSpheres);
+        return fail(RT_ERR_ARG, "rt_set_world: %zu spheres; at most %d are supported", count, kMaxSpheres);
     for (size_t i = 0; i < count; i++)
         if (spheres[i].mat_type < RT_MAT_LAMBERTIAN || spheres[i].mat_type > RT_MAT_DIELECTRIC)
             return fail(RT_ERR_ARG, "rt_set_world: sphere %zu has unsupported material type %d", i, spheres[i].mat_type);

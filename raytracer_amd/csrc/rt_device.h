@@ -24,7 +24,8 @@ constexpr int kGeomPad = 8;
 // are kept out of the filter (k = +inf) and tested exactly for every ray: big[] lists them.
 constexpr int kMaxBig = 16;
 constexpr int kQueueLdsBytes = (512 / 64) * 16 * 64 * 4;   // per workgroup: 8 waves x 16 slots x 64 lanes x u32
-constexpr int kMaxSpheres = 2048;          // 48 B/sphere of LDS per workgroup (96 KB) + 32 KB of queues
+constexpr int kMaxSpheresLds = 2048;       // up to here the per-sphere records are staged in LDS (<= 96 KB + 32 KB of queues)
+constexpr int kMaxSpheres = 1 << 20;       // beyond kMaxSpheresLds they are read from global memory
 constexpr int kBlockThreads = 512;         // 8 waves per workgroup
 
 struct Camera {                            // rt_camera, flattened
@@ -73,11 +74,11 @@ __host__ __device__ inline uint32_t part_row_at(uint32_t k, int tile_rows, int p
     return (t * (uint32_t)part_count + (uint32_t)part_index) * tr + r;
 }
 
-hipError_t launch_trace_strict(const TraceParams &p, int blocks, size_t lds_bytes, hipStream_t s);
-hipError_t launch_trace_fast(const TraceParams &p, int blocks, size_t lds_bytes, hipStream_t s);
+hipError_t launch_trace_strict(const TraceParams &p, bool geom_global, int blocks, size_t lds_bytes, hipStream_t s);
+hipError_t launch_trace_fast(const TraceParams &p, bool geom_global, int blocks, size_t lds_bytes, hipStream_t s);
 hipError_t launch_resolve(const ResolveParams &p, hipStream_t s);
-int trace_blocks_per_cu_strict(size_t lds_bytes);
-int trace_blocks_per_cu_fast(size_t lds_bytes);
+int trace_blocks_per_cu_strict(bool geom_global, size_t lds_bytes);
+int trace_blocks_per_cu_fast(bool geom_global, size_t lds_bytes);
 void trace_forget_strict();   // rt_shutdown / device change: drop the cached launch set-up
 void trace_forget_fast();
 

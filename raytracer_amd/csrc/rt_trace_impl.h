@@ -361,25 +361,34 @@ __device__ __forceinline__ void camera_ray(const TraceParams &p, Lane &L)
     set_ray<MODE>(L, org, sub(ps, org));
 }
 
-template <int MODE>
+// GEOM_GLOBAL: scenes whose geometry image does not fit the LDS next to the queues read the
+// per-sphere records (exact test, shading) from global memory through the vector L1 instead.
+template <int MODE, bool GEOM_GLOBAL>
 __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams p)
 {
     extern __shared__ float4 lds[];
-    float4 *s_geom = lds;                    // [n_pad]
-    for (int i = threadIdx.x; i < p.n_pad; i += blockDim.x) s_geom[i] = p.geom[i];
     const int lane = (int)__lane_id();
+    const float4 *s_geom, *s_matA, *s_matB;
+    uint32_t *queue;
+    if (GEOM_GLOBAL) {
+        s_geom = p.geom; s_matA = p.matA; s_matB = p.matB;
+        queue = reinterpret_cast<uint32_t *>(lds) + (threadIdx.x >> 6) * (kQueueSlots * 64);
+    } else {
+        for (int i = threadIdx.x; i < p.n_pad; i += blockDim.x) lds[i] = p.geom[i];
+        s_geom = lds;                        // [n_pad]
 #if RT_STRICT
-    float4 *s_matA = lds + p.n_pad;          // [n]
-    float4 *s_matB = s_matA + p.n;           // [n]
-    for (int i = threadIdx.x; i < p.n; i += blockDim.x) { s_matA[i] = p.matA[i]; s_matB[i] = p.matB[i]; }
-    uint32_t *queue = reinterpret_cast<uint32_t *>(s_matB + p.n) + (threadIdx.x >> 6) * (kQueueSlots * 64);
+        float4 *l_matA = lds + p.n_pad;      // [n]
+        float4 *l_matB = l_matA + p.n;       // [n]
+        for (int i = threadIdx.x; i < p.n; i += blockDim.x) { l_matA[i] = p.matA[i]; l_matB[i] = p.matB[i]; }
+        s_matA = l_matA; s_matB = l_matB;
+        queue = reinterpret_cast<uint32_t *>(l_matB + p.n) + (threadIdx.x >> 6) * (kQueueSlots * 64);
 #else
-    // The fast build spends its LDS on the candidate queues (more resident waves); the material
-    // records are read once per bounce, from global memory through the vector L1.
-    const float4 *s_matA = p.matA;
-    const float4 *s_matB = p.matB;
-    uint32_t *queue = reinterpret_cast<uint32_t *>(lds + p.n_pad) + (threadIdx.x >> 6) * (kQueueSlots * 64);
+        // The fast build spends its LDS on the candidate queues (more resident waves); the material
+        // records are read once per bounce, from global memory through the vector L1.
+        s_matA = p.matA; s_matB = p.matB;
+        queue = reinterpret_cast<uint32_t *>(lds + p.n_pad) + (threadIdx.x >> 6) * (kQueueSlots * 64);
 #endif
+    }
     __syncthreads();
 
     const uint32_t total = (uint32_t)p.total_units;

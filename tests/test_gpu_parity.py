@@ -186,7 +186,7 @@ def test_argument_errors(rt):
     with pytest.raises(rt.RtError, match="material"):
         rt.set_world(bad)
     with pytest.raises(rt.RtError, match="spheres"):
-        rt.set_world(np.zeros(5000, rt.SPHERE_DTYPE))
+        rt.set_world(np.zeros((1 << 20) + 1, rt.SPHERE_DTYPE))
     rt.set_world(load_scene("s3"))      # library still usable after errors
     assert rt.render(cam, W, H, 1, 5)["rgba"][..., 3].min() == 255
 
@@ -342,3 +342,25 @@ def test_progressive_frames_equal_one_long_render(rt):
         rt.render_progressive(cam, W, H, 3, 20, 4, strict_fp=True, seed=3)      # changed spp
     fast = [rt.render_progressive(cam, W, H, 1, 20, f, seed=3)["rgba"] for f in range(3)]
     assert np.array_equal(fast[2], rt.render(cam, W, H, 3, 20, seed=3, chunk_spp=1)["rgba"])
+
+
+def test_scene_larger_than_the_lds_image(rt):
+    """More than 2048 spheres: the per-sphere records no longer fit the LDS next to the queues and
+    are read from global memory (a separate kernel instantiation).  Same parity bars."""
+    sph = rt.scene_generate(25, 0)                      # 50x50 cells -> about 2500 spheres
+    assert len(sph) > 2048
+    rt.set_world(sph)
+    W, H = 100, 56
+    cam = rt.camera(W, H)
+    r = rt.render(cam, W, H, 2, 50, strict_fp=True, seed=8, chunk_spp=1, want_hit=True, want_accum=True)
+    c = rc.render(rc.camera(W, H), sph, W, H, 2, 50, rng=rc.RNG_COUNTER, seed=8, chunk_spp=1,
+                  want_hit=True, want_accum=True)
+    assert np.array_equal(bits(r["accum"]), bits(c["accum"]))
+    assert np.array_equal(r["hit"], c["hit"]) and r["stats"].rays == c["stats"].rays
+    d = rt.render(cam, W, H, 1, 50, mode=rt.MODE_CONST_U, strict_fp=True, want_hit=True)
+    e = rc.render(rc.camera(W, H), sph, W, H, 1, 50, rng=rc.RNG_CONST_U, want_hit=True)
+    assert np.array_equal(d["hit"], e["hit"]) and np.array_equal(d["rgba"], e["rgba"])
+    f = rt.render(cam, W, H, 256, 50, seed=1, chunk_spp=32, want_accum=True)
+    s = rt.render(cam, W, H, 256, 50, seed=2, chunk_spp=32, strict_fp=True, want_accum=True)
+    assert abs(f["accum"].mean() - s["accum"].mean()) < 0.01 * s["accum"].mean()
+    assert psnr(f["rgba"], s["rgba"]) > 27.0
