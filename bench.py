@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=16)
     ap.add_argument("--strict", type=int, default=0, help="1 = bit-reproducible build (no FMA)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-rebalance", action="store_true", help="keep the equal row-tile deal (N > 1)")
     ap.add_argument("--cpu-width", type=int, default=3840)
     ap.add_argument("--cpu-spp", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -98,9 +99,19 @@ def main():
     rt.set_world(sph)
     cam = rt.camera(W, H)
 
-    from raytracer_amd.multigpu import RowGather
-    rows = [rt.part_row_map(H, args.tile_rows, i, world) for i in range(world)]
-    rg = RowGather(rows, W, 4, torch.uint8, dev, rank, world)    # compact owned rows -> full image on rank 0
+    from raytracer_amd.multigpu import RowGather, weighted_row_maps
+
+    class Part:                                                    # the current row-tile deal
+        pass
+    part = Part()
+
+    def deal(weights):
+        part.weights = [float(w) for w in weights]
+        part.rows = weighted_row_maps(H, args.tile_rows, part.weights)
+        # compact owned rows -> full image on rank 0
+        part.rg = RowGather(part.rows, W, 4, torch.uint8, dev, rank, world)
+
+    deal([1.0] * world)                                            # equal weights = tile t -> rank t % world
 
     def sync():
         if world > 1:
@@ -108,14 +119,21 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        st = rt.render_device(cam, rg.mine.data_ptr(), W, H, args.spp, args.depth, strict_fp=bool(args.strict),
-                              seed=0, chunk_spp=args.chunk, tile_rows=args.tile_rows,
-                              part_index=rank, part_count=world)
-        rg.gather()                                                   # RCCL over xGMI when world > 1
+        st = rt.render_device(cam, part.rg.mine.data_ptr(), W, H, args.spp, args.depth,
+                              strict_fp=bool(args.strict), seed=0, chunk_spp=args.chunk, rows=part.rows[rank])
+        part.rg.gather()                                              # RCCL over xGMI when world > 1
         return st
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        st = step()
+        if i == 0 and world > 1 and not args.no_rebalance:
+            # MI355X devices hold different clocks on this compute-bound kernel (10 % apart is
+            # common): deal the row tiles in proportion to the speed each rank just showed, so
+            # that all ranks finish together.  The image does not depend on the deal.
+            speed = torch.zeros(world, dtype=torch.float64, device=dev)
+            speed[rank] = len(part.rows[rank]) / max(st.kernel_ms, 1e-6)
+            dist.all_reduce(speed, op=dist.ReduceOp.SUM)
+            deal(speed.cpu().tolist())
     sync()
     t0 = time.perf_counter()
     stats = [step() for _ in range(args.steps)]
@@ -128,7 +146,7 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        img = rg.full.cpu().numpy()
+        img = part.rg.full.cpu().numpy()
         assert (img[..., 3] == 255).all(), "framebuffer not fully written"
         samples = W * H * args.spp
         kernel_ms = float(np.mean([s.kernel_ms for s in stats]))                 # HIP events on the library's stream
@@ -151,7 +169,8 @@ def main():
                            "final" if args.scene == "sf" else "3-sphere", W, H, args.spp, args.depth),
                        "spheres": int(len(sph)), "chunk_spp": args.chunk, "tile_rows": args.tile_rows,
                        "kernel": "strict" if args.strict else "fast",
-                       "parallelism": "row-tiles x%d, RCCL gather to rank 0" % world},
+                       "parallelism": "row-tiles x%d, RCCL gather to rank 0" % world,
+                       "rows_per_rank": [int(len(r)) for r in part.rows]},
             "roofline": {"bound": "valu_fp32", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
                          # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this

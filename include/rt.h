@@ -108,6 +108,12 @@ typedef struct rt_opts {
     float   *accum_out;      /* optional, width*height*3: linear mean colour (before
                                 gamma and quantisation)                              */
     rt_stats *stats;         /* optional                                             */
+    const uint32_t *rows;    /* optional explicit partition (HOST pointer): the image rows
+                                this call renders, strictly ascending; overrides
+                                part_index / part_count.  Lets a multi-GPU caller deal row
+                                tiles in proportion to measured GPU speed.  Compact device
+                                buffers then hold row_count rows in this order           */
+    uint32_t row_count;
 } rt_opts;
 
 enum rt_status {

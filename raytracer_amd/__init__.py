@@ -48,7 +48,8 @@ class Opts(C.Structure):
     _fields_ = [("mode", C.c_int32), ("strict_fp", C.c_int32), ("seed", C.c_uint32),
                 ("sample_base", C.c_uint32), ("chunk_spp", C.c_int32), ("tile_rows", C.c_int32),
                 ("part_index", C.c_int32), ("part_count", C.c_int32),
-                ("hit_index_out", C.c_void_p), ("accum_out", C.c_void_p), ("stats", C.c_void_p)]
+                ("hit_index_out", C.c_void_p), ("accum_out", C.c_void_p), ("stats", C.c_void_p),
+                ("rows", C.c_void_p), ("row_count", C.c_uint32)]
 
 
 # numpy view of rt_sphere: sphere_t + material_t of the reference (Main.c:53-59, 74-79), 40 bytes
@@ -169,8 +170,12 @@ def part_row_map(height, tile_rows, part_index, part_count):
                     dtype=np.int64)
 
 
-def _opts(mode, strict_fp, seed, sample_base, chunk_spp, tile_rows, part_index, part_count):
+def _opts(mode, strict_fp, seed, sample_base, chunk_spp, tile_rows, part_index, part_count, rows=None):
     o = Opts()
+    if rows is not None:
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        o._rows_keepalive = rows
+        o.rows, o.row_count = rows.ctypes.data, len(rows)
     o.mode, o.strict_fp, o.seed, o.sample_base = mode, int(bool(strict_fp)), seed, sample_base
     o.chunk_spp, o.tile_rows, o.part_index, o.part_count = chunk_spp, tile_rows, part_index, part_count
     return o
@@ -178,14 +183,14 @@ def _opts(mode, strict_fp, seed, sample_base, chunk_spp, tile_rows, part_index, 
 
 def render(cam, width, height, spp, max_depth, mode=MODE_MC, strict_fp=False, seed=0, sample_base=0,
            chunk_spp=0, tile_rows=0, part_index=0, part_count=0, want_hit=False, want_accum=False,
-           out=None):
+           out=None, rows=None):
     """rt_render into host memory.  Returns dict(rgba, hit, accum, stats)."""
     rgba = out if out is not None else np.zeros((height, width, 4), dtype=np.uint8)
     assert rgba.dtype == np.uint8 and rgba.shape == (height, width, 4) and rgba.flags.c_contiguous
     hit = np.full((height, width), -2, dtype=np.int32) if want_hit else None
     acc = np.zeros((height, width, 3), dtype=np.float32) if want_accum else None
     st = Stats()
-    o = _opts(mode, strict_fp, seed, sample_base, chunk_spp, tile_rows, part_index, part_count)
+    o = _opts(mode, strict_fp, seed, sample_base, chunk_spp, tile_rows, part_index, part_count, rows)
     o.hit_index_out = hit.ctypes.data if want_hit else None
     o.accum_out = acc.ctypes.data if want_accum else None
     o.stats = C.addressof(st)
@@ -210,10 +215,10 @@ def render_progressive(cam, width, height, spp, max_depth, frame_index, mode=MOD
 
 def render_device(cam, rgba_dev_ptr, width, height, spp, max_depth, mode=MODE_MC, strict_fp=False,
                   seed=0, sample_base=0, chunk_spp=0, tile_rows=0, part_index=0, part_count=0,
-                  hit_dev_ptr=None, accum_dev_ptr=None):
+                  hit_dev_ptr=None, accum_dev_ptr=None, rows=None):
     """rt_render_device: outputs are raw device pointers (e.g. torch.Tensor.data_ptr())."""
     st = Stats()
-    o = _opts(mode, strict_fp, seed, sample_base, chunk_spp, tile_rows, part_index, part_count)
+    o = _opts(mode, strict_fp, seed, sample_base, chunk_spp, tile_rows, part_index, part_count, rows)
     o.hit_index_out = hit_dev_ptr
     o.accum_out = accum_dev_ptr
     o.stats = C.addressof(st)

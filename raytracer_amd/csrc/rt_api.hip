@@ -27,7 +27,10 @@ struct DevBuf {
     {
         if (bytes <= cap) return hipSuccess;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        hipError_t e = hipMalloc(&p, bytes);
+        const size_t want = bytes + bytes / 4;          // headroom: a slightly larger partition must not reallocate
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) { cap = want; return e; }
+        e = hipMalloc(&p, bytes);
         if (e == hipSuccess) cap = bytes;
         return e;
     }
@@ -47,7 +50,7 @@ struct State {
     float c_near = 0.0f;
     DevBuf geom, matA, matB, pairs;
     // scratch
-    DevBuf partial, counters, rgba, accum, hit;
+    DevBuf partial, counters, rgba, accum, hit, rows;
     // progressive accumulation (rt_render_progressive): running per-pixel sums and what they belong to
     DevBuf running;
     uint32_t prog_w = 0, prog_h = 0, prog_npix = 0, prog_frames = 0;
@@ -121,7 +124,14 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
 
     HIP_TRY(hipSetDevice(g.device));
 
-    const uint32_t rows = rt_part_rows(height, tile_rows, part_index, part_count);
+    const bool explicit_rows = o.rows != nullptr;
+    if (explicit_rows) {
+        if (o.row_count > height) return fail(RT_ERR_ARG, "rt_render: row_count %u exceeds the image height %u", o.row_count, height);
+        for (uint32_t k = 0; k < o.row_count; k++)
+            if (o.rows[k] >= height || (k > 0 && o.rows[k] <= o.rows[k - 1]))
+                return fail(RT_ERR_ARG, "rt_render: rows[] must be strictly ascending and below the image height (entry %u)", k);
+    }
+    const uint32_t rows = explicit_rows ? o.row_count : rt_part_rows(height, tile_rows, part_index, part_count);
     const uint32_t npix = rows * width;
     const int chunk = (o.chunk_spp > 0 && o.chunk_spp < spp) ? o.chunk_spp : spp;
     const int nchunks = (spp + chunk - 1) / chunk;
@@ -182,6 +192,12 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
             tp.nbig = g.nbig; memcpy(tp.big, g.big, sizeof tp.big); tp.c_near = g.c_near;
             tp.width = width; tp.height = height; tp.npix = npix;
             tp.tile_rows = tile_rows; tp.part_index = part_index; tp.part_count = part_count;
+            tp.rows = nullptr;
+            if (explicit_rows) {
+                HIP_TRY(g.rows.reserve((size_t)rows * sizeof(uint32_t)));
+                HIP_TRY(hipMemcpyAsync(g.rows.p, o.rows, (size_t)rows * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+                tp.rows = (const uint32_t *)g.rows.p;
+            }
             tp.spp = spp; tp.chunk_spp = chunk; tp.nchunks = nchunks; tp.max_depth = max_depth;
             tp.mode = o.mode; tp.seed = o.seed; tp.sample_base = sample_base;
             tp.partial = (float4 *)g.partial.p;
@@ -227,7 +243,7 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
 
     if (!device_ptrs) {
         for (uint32_t k = 0; k < rows; k++) {
-            const uint32_t y = rt_part_row_at(k, tile_rows, part_index, part_count);
+            const uint32_t y = explicit_rows ? o.rows[k] : rt_part_row_at(k, tile_rows, part_index, part_count);
             memcpy(rgba + (size_t)y * width * 4, g.h_rgba.data() + (size_t)k * width * 4, (size_t)width * 4);
             if (o.accum_out) memcpy(o.accum_out + (size_t)y * width * 3, g.h_accum.data() + (size_t)k * width * 3, (size_t)width * 12);
             if (o.hit_index_out) memcpy(o.hit_index_out + (size_t)y * width, g.h_hit.data() + (size_t)k * width, (size_t)width * 4);
@@ -496,7 +512,7 @@ void rt_shutdown(void)
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     g.geom.release(); g.matA.release(); g.matB.release(); g.pairs.release();
-    g.partial.release(); g.running.release(); g.counters.release(); g.rgba.release(); g.accum.release(); g.hit.release();
+    g.partial.release(); g.running.release(); g.rows.release(); g.counters.release(); g.rgba.release(); g.accum.release(); g.hit.release();
     if (g.ev0) (void)hipEventDestroy(g.ev0);
     if (g.ev1) (void)hipEventDestroy(g.ev1);
     if (g.ev2) (void)hipEventDestroy(g.ev2);

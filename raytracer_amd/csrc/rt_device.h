@@ -46,6 +46,7 @@ struct TraceParams {
     uint32_t width, height;                // full image
     uint32_t npix;                         // owned pixels = owned_rows * width
     int tile_rows, part_index, part_count; // owned row k -> image row, see part_row_at()
+    const uint32_t *rows;                  // or, if not null, rows[k] (explicit partition)
     int spp, chunk_spp, nchunks, max_depth;
     int mode;                              // RT_MODE_*
     uint32_t seed, sample_base;

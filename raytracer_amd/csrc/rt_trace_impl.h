@@ -436,7 +436,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
                     divmod(L.pixc, p.width, inv_width, rowk, L.x);
                     L.chunk = (int)chunk_u;
 #endif
-                    L.y = part_row_at(rowk, p.tile_rows, p.part_index, p.part_count);
+                    L.y = p.rows ? p.rows[rowk] : part_row_at(rowk, p.tile_rows, p.part_index, p.part_count);
                     L.pixhash = mix32((L.x + L.y * p.width) + mix32(p.seed ^ 0x6A09E667U));
                     L.s = L.chunk * p.chunk_spp;
                     int e = L.s + p.chunk_spp;

@@ -10,6 +10,28 @@ import torch
 import torch.distributed as dist
 
 
+def weighted_row_maps(height, tile_rows, weights):
+    """Deal the row tiles of an image to ranks in proportion to `weights` (e.g. measured GPU
+    speeds), keeping every rank's tiles spread over the whole image (smooth weighted round robin:
+    each tile goes to the rank with the largest accumulated credit).  Equal weights give the
+    t % world == rank deal of rt_part_row_at.  Returns one ascending row array per rank."""
+    import numpy as np
+    world = len(weights)
+    w = np.asarray(weights, dtype=np.float64)
+    if world == 0 or not np.all(np.isfinite(w)) or np.any(w <= 0):
+        raise ValueError("weights must be positive and finite")
+    w = w / w.sum()
+    credit = np.zeros(world)
+    rows = [[] for _ in range(world)]
+    ntiles = (height + tile_rows - 1) // tile_rows
+    for t in range(ntiles):
+        credit += w
+        r = int(np.argmax(credit - 1e-12 * np.arange(world)))     # ties: lowest rank
+        credit[r] -= 1.0
+        rows[r].extend(range(t * tile_rows, min(height, (t + 1) * tile_rows)))
+    return [np.asarray(r, dtype=np.int64) for r in rows]
+
+
 class RowGather:
     def __init__(self, row_maps, width, channels, dtype, device, rank, world):
         """row_maps[i] = image rows owned by rank i (ascending), e.g. raytracer_amd.part_row_map."""

@@ -364,3 +364,27 @@ def test_scene_larger_than_the_lds_image(rt):
     s = rt.render(cam, W, H, 256, 50, seed=2, chunk_spp=32, strict_fp=True, want_accum=True)
     assert abs(f["accum"].mean() - s["accum"].mean()) < 0.01 * s["accum"].mean()
     assert psnr(f["rgba"], s["rgba"]) > 27.0
+
+
+def test_explicit_row_lists_assemble_to_the_full_image(rt):
+    """opts->rows: an arbitrary ascending row list per call (what a speed-weighted multi-GPU deal
+    produces); host and device entries, compact device layout."""
+    import torch
+    from raytracer_amd.multigpu import weighted_row_maps
+    _, W, H = load_camera_golden(400)
+    rt.set_world(load_scene("sf"))
+    cam = rt.camera(W, H)
+    full = rt.render(cam, W, H, 3, 20, seed=4, chunk_spp=2, strict_fp=True)["rgba"]
+    maps = weighted_row_maps(H, 16, [1.0, 0.6, 1.3])
+    out = np.zeros((H, W, 4), np.uint8)
+    for m in maps:
+        rt.render(cam, W, H, 3, 20, seed=4, chunk_spp=2, strict_fp=True, rows=m, out=out)
+    assert np.array_equal(out, full)
+    dev = torch.zeros((len(maps[2]), W, 4), dtype=torch.uint8, device="cuda:0")
+    rt.render_device(cam, dev.data_ptr(), W, H, 3, 20, seed=4, chunk_spp=2, strict_fp=True, rows=maps[2])
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.cpu().numpy(), full[maps[2]])
+    with pytest.raises(rt.RtError, match="ascending"):
+        rt.render(cam, W, H, 1, 5, rows=[5, 5, 6])
+    with pytest.raises(rt.RtError, match="ascending"):
+        rt.render(cam, W, H, 1, 5, rows=[0, H])
