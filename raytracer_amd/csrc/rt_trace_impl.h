@@ -145,12 +145,24 @@ __device__ __forceinline__ V3 refract(V3 v, V3 n, float e)
 // with the same distributions (uniform on the unit sphere / in the unit disk); no loop, so the
 // lanes of a wave do not wait for the slowest rejection chain.  v_sin/v_cos take revolutions.
 // In constant-u mode the reference's loops reject u = 0.5 a hundred times and return zero.
+// Two uniforms in [0,1) from one 32-bit draw, 16 bits each (the reference's RAND_FLOAT has 15).
+template <int MODE>
+__device__ __forceinline__ void rng_float2(Rng &r, float &u0, float &u1)
+{
+    if (MODE == 1) { u0 = 0.5f; u1 = 0.5f; return; }
+    const uint32_t x = mix32(r.key + r.n * 0x9E3779B9U);
+    r.n++;
+    u0 = (float)(x >> 16) * (1.0f / 65536.0f);
+    u1 = (float)(x & 0xffffu) * (1.0f / 65536.0f);
+}
+
 template <int MODE>
 __device__ __forceinline__ V3 sphere_direction(Rng &r)
 {
     if (MODE == 1) return v3(0.0f, 0.0f, 0.0f);
-    const float z = fmaf(-2.0f, rng_float<MODE>(r), 1.0f);
-    const float phi = rng_float<MODE>(r);
+    float u, phi;
+    rng_float2<MODE>(r, u, phi);
+    const float z = fmaf(-2.0f, u, 1.0f);
     const float rad = rt_sqrt(fmaxf(0.0f, fmaf(-z, z, 1.0f)));
     return v3(rad * __builtin_amdgcn_cosf(phi), rad * __builtin_amdgcn_sinf(phi), z);
 }
@@ -159,8 +171,9 @@ template <int MODE>
 __device__ __forceinline__ void disk_point(Rng &r, float &x, float &y)
 {
     if (MODE == 1) { x = 0.0f; y = 0.0f; return; }
-    const float rad = rt_sqrt(rng_float<MODE>(r));
-    const float phi = rng_float<MODE>(r);
+    float u, phi;
+    rng_float2<MODE>(r, u, phi);
+    const float rad = rt_sqrt(u);
     x = rad * __builtin_amdgcn_cosf(phi);
     y = rad * __builtin_amdgcn_sinf(phi);
 }
@@ -338,8 +351,14 @@ template <int MODE>
 __device__ __forceinline__ void camera_ray(const TraceParams &p, Lane &L)
 {
     const Camera &c = p.cam;
+#if RT_STRICT
     float offx = rng_float<MODE>(L.rng) - 0.5f;
     float offy = rng_float<MODE>(L.rng) - 0.5f;
+#else
+    float offx, offy;
+    rng_float2<MODE>(L.rng, offx, offy);
+    offx -= 0.5f; offy -= 0.5f;
+#endif
     float fx = (float)(int)L.x + offx;
     float fy = (float)(int)L.y + offy;
     V3 ps;
