@@ -69,6 +69,10 @@ def main():
     ap.add_argument("--strict", type=int, default=0, help="1 = bit-reproducible build (no FMA)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-rebalance", action="store_true", help="keep the equal row-tile deal (N > 1)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo stages the gather through host memory (rehearsal only)")
+    ap.add_argument("--shared-gpu", action="store_true",
+                    help="rehearsal of the N > 1 path on a one-GPU box: every rank uses device 0 (needs --backend gloo)")
     ap.add_argument("--cpu-width", type=int, default=3840)
     ap.add_argument("--cpu-spp", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -86,11 +90,19 @@ def main():
                          % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the HIP path has no CPU fallback")
+    if args.shared_gpu:
+        if args.backend != "gloo":
+            raise SystemExit("bench.py: --shared-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")     # where small collectives live
 
     W = args.width
     H = rt.height_for(W)
@@ -109,7 +121,7 @@ def main():
         part.weights = [float(w) for w in weights]
         part.rows = weighted_row_maps(H, args.tile_rows, part.weights)
         # compact owned rows -> full image on rank 0
-        part.rg = RowGather(part.rows, W, 4, torch.uint8, dev, rank, world)
+        part.rg = RowGather(part.rows, W, 4, torch.uint8, dev, rank, world, via_host=(args.backend == "gloo"))
 
     deal([1.0] * world)                                            # equal weights = tile t -> rank t % world
 
@@ -130,7 +142,7 @@ def main():
             # MI355X devices hold different clocks on this compute-bound kernel (10 % apart is
             # common): deal the row tiles in proportion to the speed each rank just showed, so
             # that all ranks finish together.  The image does not depend on the deal.
-            speed = torch.zeros(world, dtype=torch.float64, device=dev)
+            speed = torch.zeros(world, dtype=torch.float64, device=coll_dev)
             speed[rank] = len(part.rows[rank]) / max(st.kernel_ms, 1e-6)
             dist.all_reduce(speed, op=dist.ReduceOp.SUM)
             deal(speed.cpu().tolist())
@@ -141,7 +153,7 @@ def main():
     dt = time.perf_counter() - t0
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -169,7 +181,9 @@ def main():
                            "final" if args.scene == "sf" else "3-sphere", W, H, args.spp, args.depth),
                        "spheres": int(len(sph)), "chunk_spp": args.chunk, "tile_rows": args.tile_rows,
                        "kernel": "strict" if args.strict else "fast",
-                       "parallelism": "row-tiles x%d, RCCL gather to rank 0" % world,
+                       "parallelism": "row-tiles x%d, %s gather to rank 0%s" % (
+                           world, "RCCL" if args.backend == "nccl" else "gloo (host-staged)",
+                           ", all ranks on ONE gpu (rehearsal)" if args.shared_gpu else ""),
                        "rows_per_rank": [int(len(r)) for r in part.rows]},
             "roofline": {"bound": "valu_fp32", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),

@@ -258,6 +258,10 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
             unsigned long long c[8] = {0};
             HIP_TRY(hipMemcpy(c, g.counters.p, sizeof c, hipMemcpyDeviceToHost));
             st.rays = c[1];
+#ifdef RT_DIAG
+            fprintf(stderr, "diag: wave scans %llu, pair branches taken %.1f, drain iterations %.2f, drained candidates %.2f (per wave scan)\n",
+                    c[5], (double)c[2] / c[5], (double)c[4] / c[5], (double)c[3] / c[5]);
+#endif
             st.sphere_tests = c[1] * (uint64_t)g.n;
             float ms = 0.0f;
             HIP_TRY(hipEventElapsedTime(&ms, g.ev0, g.ev1));

@@ -236,6 +236,16 @@ __device__ __forceinline__ void exact_test(const float4 *s_geom, int i, Probe &q
 #endif
 }
 
+#ifdef RT_DIAG
+// Diagnostic build only: where the non-scan instructions go.
+struct Diag { uint32_t branches, appends, drain_iters, drain_lanes, scans; };
+#define RT_DIAG_ARG , Diag &dg
+#define RT_DIAG_PASS , dg
+#else
+#define RT_DIAG_ARG
+#define RT_DIAG_PASS
+#endif
+
 constexpr int kQueueSlots = 16;            // per lane
 constexpr int kPairBatch = 4;              // pairs between two queue-overflow checks
 static_assert(kQueueLdsBytes == (kBlockThreads / 64) * kQueueSlots * 64 * 4, "host and kernel disagree on the queue size");
@@ -243,10 +253,14 @@ static_assert(kGeomPad == 2 * kPairBatch, "the sphere list is padded to whole ba
 
 // Exact test of the queued candidates of every lane of the wave; queue[j * 64 + lane] is the
 // j-th sphere index the lane queued (slot-major: a lane's LDS bank does not depend on j).
-__device__ __forceinline__ void drain(const float4 *s_geom, const uint32_t *queue, int cnt, int lane, Probe &q)
+__device__ __forceinline__ void drain(const float4 *s_geom, const uint32_t *queue, int cnt, int lane, Probe &q RT_DIAG_ARG)
 {
-    for (int j = 0; __ballot(j < cnt) != 0ULL; j++)
+    for (int j = 0; __ballot(j < cnt) != 0ULL; j++) {
+#ifdef RT_DIAG
+        dg.drain_iters++; dg.drain_lanes += (uint32_t)__popcll(__ballot(j < cnt));
+#endif
         if (j < cnt) exact_test(s_geom, (int)queue[j * 64 + lane], q);
+    }
 }
 
 // hit() (Main.c:688-713) as filter + exact test.
@@ -261,7 +275,7 @@ __device__ __forceinline__ void drain(const float4 *s_geom, const uint32_t *queu
 // rest would inflate slack for everybody and are tested exactly for every ray instead (big[]).
 template <bool CULL_BEHIND>
 __device__ __forceinline__ void scan_spheres(const TraceParams &p, const float4 *s_geom, uint32_t *queue, int lane,
-                                             float ux, float uy, float uz, float slack_scale, Probe &q)
+                                             float ux, float uy, float uz, float slack_scale, Probe &q RT_DIAG_ARG)
 {
     for (int b = 0; b < p.nbig; b++) exact_test(s_geom, p.big[b], q);
 
@@ -293,6 +307,9 @@ __device__ __forceinline__ void scan_spheres(const TraceParams &p, const float4 
             // the sphere; with h < 0 the sphere then lies behind it and is not queued.  (The
             // empty asm keeps that second test inside the rarely taken branch.)
             if (__ballot(px || py) != 0ULL) {
+#ifdef RT_DIAG
+                dg.branches++;
+#endif
                 if (px) {
                     float hh = h.x, mm = m.x;
                     asm volatile("" : "+v"(hh), "+v"(mm));
@@ -306,11 +323,14 @@ __device__ __forceinline__ void scan_spheres(const TraceParams &p, const float4 
             }
         }
         if (__ballot(cnt > kQueueSlots - 2 * kPairBatch) != 0ULL) {
-            drain(s_geom, queue, cnt, lane, q);
+            drain(s_geom, queue, cnt, lane, q RT_DIAG_PASS);
             cnt = 0;
         }
     }
-    drain(s_geom, queue, cnt, lane, q);
+#ifdef RT_DIAG
+    dg.scans++;
+#endif
+    drain(s_geom, queue, cnt, lane, q RT_DIAG_PASS);
 }
 
 struct Lane {
@@ -427,6 +447,9 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
     bool need_unit = true;     // lane must pull a new work unit
     bool need_sample = true;   // lane must start a new sample
     uint32_t rays = 0;
+#ifdef RT_DIAG
+    Diag dg = {0, 0, 0, 0, 0};
+#endif
 
     for (;;) {
         // ---- pull work units: one atomic per wave ------------------------------------
@@ -491,7 +514,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
             // discriminant h*h - a*c that decides in exact_test.
             q.a = q.dx * q.dx + q.dy * q.dy + q.dz * q.dz;
             const float inv = (q.a > 0.0f) ? __builtin_amdgcn_rsqf(q.a) : 0.0f;
-            scan_spheres<false>(p, s_geom, queue, lane, q.dx * inv, q.dy * inv, q.dz * inv, 7.6293945e-6f, q);
+            scan_spheres<false>(p, s_geom, queue, lane, q.dx * inv, q.dy * inv, q.dz * inv, 7.6293945e-6f, q RT_DIAG_PASS);
             if (!(q.a > 0.0f)) {
                 // a zero or NaN direction gives the filter nothing to work with: test everything
                 q.closest = 3.402823466e+38f; q.hit = -1;
@@ -499,7 +522,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
             }
         }
 #else
-        scan_spheres<true>(p, s_geom, queue, lane, q.dx, q.dy, q.dz, 1.9073486e-6f, q);   // 2^-19
+        scan_spheres<true>(p, s_geom, queue, lane, q.dx, q.dy, q.dz, 1.9073486e-6f, q RT_DIAG_PASS);   // 2^-19
         if (L.zero_dir) q.hit = -1;
 #endif
         const float closest = q.closest;
@@ -613,6 +636,14 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
     unsigned long long r64 = rays;
     for (int off = 32; off > 0; off >>= 1) r64 += __shfl_down(r64, off);
     if (__lane_id() == 0) atomicAdd(&p.counters[1], r64);
+#ifdef RT_DIAG
+    if (__lane_id() == 0) {
+        atomicAdd(&p.counters[2], (unsigned long long)dg.branches);
+        atomicAdd(&p.counters[3], (unsigned long long)dg.drain_lanes);
+        atomicAdd(&p.counters[4], (unsigned long long)dg.drain_iters);
+        atomicAdd(&p.counters[5], (unsigned long long)dg.scans);
+    }
+#endif
 }
 
 }  // namespace RT_NS

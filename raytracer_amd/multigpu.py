@@ -33,9 +33,12 @@ def weighted_row_maps(height, tile_rows, weights):
 
 
 class RowGather:
-    def __init__(self, row_maps, width, channels, dtype, device, rank, world):
-        """row_maps[i] = image rows owned by rank i (ascending), e.g. raytracer_amd.part_row_map."""
+    def __init__(self, row_maps, width, channels, dtype, device, rank, world, via_host=False):
+        """row_maps[i] = image rows owned by rank i (ascending), e.g. raytracer_amd.part_row_map.
+        via_host: the process group cannot move device tensors (gloo with GPU buffers, used to
+        rehearse the N > 1 path on a one-GPU box): stage the rows through host memory."""
         self.rank, self.world = rank, world
+        self.via_host = bool(via_host) and torch.device(device).type != "cpu"
         self.counts = [len(r) for r in row_maps]
         self.max_rows = max(self.counts) if self.counts else 0
         height = sum(self.counts)
@@ -45,11 +48,21 @@ class RowGather:
         self.recv = ([torch.zeros_like(self.mine) for _ in range(world)]
                      if (rank == 0 and world > 1) else None)
         self.idx = [torch.as_tensor(r, dtype=torch.int64, device=device) for r in row_maps] if rank == 0 else None
+        if self.via_host and world > 1:
+            self.host_mine = torch.zeros(self.mine.shape, dtype=dtype)
+            self.host_recv = [torch.zeros_like(self.host_mine) for _ in range(world)] if rank == 0 else None
 
     def gather(self):
         """Collect self.mine from all ranks into self.full on rank 0."""
         if self.world > 1:
-            dist.gather(self.mine, self.recv, dst=0)
+            if self.via_host:
+                self.host_mine.copy_(self.mine)
+                dist.gather(self.host_mine, self.host_recv, dst=0)
+                if self.rank == 0:
+                    for i in range(self.world):
+                        self.recv[i].copy_(self.host_recv[i])
+            else:
+                dist.gather(self.mine, self.recv, dst=0)
             if self.rank == 0:
                 for i in range(self.world):
                     self.full.index_copy_(0, self.idx[i], self.recv[i][:self.counts[i]])
