@@ -206,7 +206,7 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
             tp.total_units = units;
 
             const bool geom_global = g.n > kMaxSpheresLds;
-            const size_t lds = (geom_global ? 0 : (o.strict_fp ? ((size_t)g.n_pad + 2 * (size_t)g.n) : (size_t)g.n_pad) * sizeof(float4)) + kQueueLdsBytes;
+            const size_t lds = (geom_global ? 0 : (size_t)g.n_pad * sizeof(float4)) + kQueueLdsBytes;
             const int per_cu = o.strict_fp ? trace_blocks_per_cu_strict(geom_global, lds) : trace_blocks_per_cu_fast(geom_global, lds);
             uint64_t blocks = (uint64_t)g.num_cu * (uint64_t)per_cu;
             const uint64_t need = (units + kBlockThreads - 1) / kBlockThreads;
@@ -259,8 +259,9 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
             HIP_TRY(hipMemcpy(c, g.counters.p, sizeof c, hipMemcpyDeviceToHost));
             st.rays = c[1];
 #ifdef RT_DIAG
-            fprintf(stderr, "diag: wave scans %llu, pair branches taken %.1f, drain iterations %.2f, drained candidates %.2f (per wave scan)\n",
-                    c[5], (double)c[2] / c[5], (double)c[4] / c[5], (double)c[3] / c[5]);
+            fprintf(stderr, "diag: wave scans %llu; per wave scan: pair branches taken %.1f, filter passes %.1f, "
+                    "queued candidates %.2f, drain iterations %.2f\n",
+                    c[5], (double)c[2] / c[5], (double)c[7] / c[5], (double)c[3] / c[5], (double)c[4] / c[5]);
 #endif
             st.sphere_tests = c[1] * (uint64_t)g.n;
             float ms = 0.0f;

@@ -238,7 +238,7 @@ __device__ __forceinline__ void exact_test(const float4 *s_geom, int i, Probe &q
 
 #ifdef RT_DIAG
 // Diagnostic build only: where the non-scan instructions go.
-struct Diag { uint32_t branches, appends, drain_iters, drain_lanes, scans; };
+struct Diag { uint32_t branches, passes, drain_iters, drain_lanes, scans; };
 #define RT_DIAG_ARG , Diag &dg
 #define RT_DIAG_PASS , dg
 #else
@@ -273,7 +273,6 @@ __device__ __forceinline__ void drain(const float4 *s_geom, const uint32_t *queu
 // (|O| + max|C|)^2): a sphere the exact test would accept is never dropped.  A pass only queues
 // the sphere's index; the exact test runs on the queue afterwards.  Spheres much larger than the
 // rest would inflate slack for everybody and are tested exactly for every ray instead (big[]).
-template <bool CULL_BEHIND>
 __device__ __forceinline__ void scan_spheres(const TraceParams &p, const float4 *s_geom, uint32_t *queue, int lane,
                                              float ux, float uy, float uz, float slack_scale, Probe &q RT_DIAG_ARG)
 {
@@ -303,23 +302,14 @@ __device__ __forceinline__ void scan_spheres(const TraceParams &p, const float4 
             const f2 e = __builtin_elementwise_fma(h, h, m);
             const bool px = e.x >= s[6], py = e.y >= s[7];
             // One wave-uniform branch per pair keeps the common no-pass case at two compares
-            // and one scalar branch.  Inside (fast build): m < k means the origin is outside
-            // the sphere; with h < 0 the sphere then lies behind it and is not queued.  (The
-            // empty asm keeps that second test inside the rarely taken branch.)
+            // and one scalar branch.
             if (__ballot(px || py) != 0ULL) {
 #ifdef RT_DIAG
                 dg.branches++;
+                dg.passes += (uint32_t)(__popcll(__ballot(px)) + __popcll(__ballot(py)));
 #endif
-                if (px) {
-                    float hh = h.x, mm = m.x;
-                    asm volatile("" : "+v"(hh), "+v"(mm));
-                    if (!CULL_BEHIND || !(hh < 0.0f && mm < s[6])) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u)); cnt++; }
-                }
-                if (py) {
-                    float hh = h.y, mm = m.y;
-                    asm volatile("" : "+v"(hh), "+v"(mm));
-                    if (!CULL_BEHIND || !(hh < 0.0f && mm < s[7])) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u) + 1); cnt++; }
-                }
+                if (px) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u)); cnt++; }
+                if (py) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u) + 1); cnt++; }
             }
         }
         if (__ballot(cnt > kQueueSlots - 2 * kPairBatch) != 0ULL) {
@@ -403,7 +393,7 @@ __device__ __forceinline__ void camera_ray(const TraceParams &p, Lane &L)
 // GEOM_GLOBAL: scenes whose geometry image does not fit the LDS next to the queues read the
 // per-sphere records (exact test, shading) from global memory through the vector L1 instead.
 template <int MODE, bool GEOM_GLOBAL>
-__global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams p)
+__global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(const TraceParams p)
 {
     extern __shared__ float4 lds[];
     const int lane = (int)__lane_id();
@@ -415,18 +405,10 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
     } else {
         for (int i = threadIdx.x; i < p.n_pad; i += blockDim.x) lds[i] = p.geom[i];
         s_geom = lds;                        // [n_pad]
-#if RT_STRICT
-        float4 *l_matA = lds + p.n_pad;      // [n]
-        float4 *l_matB = l_matA + p.n;       // [n]
-        for (int i = threadIdx.x; i < p.n; i += blockDim.x) { l_matA[i] = p.matA[i]; l_matB[i] = p.matB[i]; }
-        s_matA = l_matA; s_matB = l_matB;
-        queue = reinterpret_cast<uint32_t *>(l_matB + p.n) + (threadIdx.x >> 6) * (kQueueSlots * 64);
-#else
-        // The fast build spends its LDS on the candidate queues (more resident waves); the material
-        // records are read once per bounce, from global memory through the vector L1.
+        // The LDS goes to the geometry image and the candidate queues (more resident waves); the
+        // material records are read once per bounce, from global memory through the vector L1.
         s_matA = p.matA; s_matB = p.matB;
         queue = reinterpret_cast<uint32_t *>(lds + p.n_pad) + (threadIdx.x >> 6) * (kQueueSlots * 64);
-#endif
     }
     __syncthreads();
 
@@ -514,7 +496,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
             // discriminant h*h - a*c that decides in exact_test.
             q.a = q.dx * q.dx + q.dy * q.dy + q.dz * q.dz;
             const float inv = (q.a > 0.0f) ? __builtin_amdgcn_rsqf(q.a) : 0.0f;
-            scan_spheres<false>(p, s_geom, queue, lane, q.dx * inv, q.dy * inv, q.dz * inv, 7.6293945e-6f, q RT_DIAG_PASS);
+            scan_spheres(p, s_geom, queue, lane, q.dx * inv, q.dy * inv, q.dz * inv, 7.6293945e-6f, q RT_DIAG_PASS);
             if (!(q.a > 0.0f)) {
                 // a zero or NaN direction gives the filter nothing to work with: test everything
                 q.closest = 3.402823466e+38f; q.hit = -1;
@@ -522,7 +504,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
             }
         }
 #else
-        scan_spheres<true>(p, s_geom, queue, lane, q.dx, q.dy, q.dz, 1.9073486e-6f, q RT_DIAG_PASS);   // 2^-19
+        scan_spheres(p, s_geom, queue, lane, q.dx, q.dy, q.dz, 1.9073486e-6f, q RT_DIAG_PASS);   // 2^-19
         if (L.zero_dir) q.hit = -1;
 #endif
         const float closest = q.closest;
@@ -595,7 +577,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
                 const float eps = 1e-8f;
                 if (fabsf(nd_l.x) < eps && fabsf(nd_l.y) < eps && fabsf(nd_l.z) < eps) nd_l = n;
                 // Metal
-                const V3 nd_m = add(unit(refl), scale(rnd, mA.w));
+                const V3 nd_m = add(refl, scale(rnd, mA.w));                // |refl| = 1: d and n are unit vectors
                 // Dielectric
                 const float ri = front ? __builtin_amdgcn_rcpf(mB.x) : mB.x;
                 const float cos_theta = fminf(cosi, 1.0f);
@@ -613,7 +595,11 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
                 if (L.bounce >= p.max_depth) done = true;
 #endif
             } else {                                                        // sky, Main.c:744-758
+#if RT_STRICT
                 const V3 ud = unit(L.d);
+#else
+                const V3 ud = L.d;                                          // already unit length (or zero)
+#endif
                 const float t = 0.5f * (ud.y + 1.0f);
                 const float w = 1.0f - t;
                 const V3 sky = v3(1.0f * w + 0.5f * t, 1.0f * w + 0.7f * t, 1.0f * w + 1.0f * t);
@@ -642,6 +628,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceParams 
         atomicAdd(&p.counters[3], (unsigned long long)dg.drain_lanes);
         atomicAdd(&p.counters[4], (unsigned long long)dg.drain_iters);
         atomicAdd(&p.counters[5], (unsigned long long)dg.scans);
+        atomicAdd(&p.counters[7], (unsigned long long)dg.passes);
     }
 #endif
 }
