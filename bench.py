@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--spp", type=int, default=1000)
     ap.add_argument("--depth", type=int, default=50)
-    ap.add_argument("--chunk", type=int, default=50, help="samples per work unit")
+    ap.add_argument("--chunk", type=int, default=-1, help="samples per work unit (-1: the library chooses)")
     ap.add_argument("--tile-rows", type=int, default=16)
     ap.add_argument("--strict", type=int, default=0, help="1 = bit-reproducible build (no FMA)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -179,7 +179,7 @@ def main():
             "data": "synthetic (the reference's generated %d-sphere scene, committed fixture)" % len(sph),
             "config": {"workload": "RTIOW %s scene %dx%d, %d spp, depth %d" % (
                            "final" if args.scene == "sf" else "3-sphere", W, H, args.spp, args.depth),
-                       "spheres": int(len(sph)), "chunk_spp": args.chunk, "tile_rows": args.tile_rows,
+                       "spheres": int(len(sph)), "chunk_spp": int(stats[-1].chunk_spp), "tile_rows": args.tile_rows,
                        "kernel": "strict" if args.strict else "fast",
                        "parallelism": "row-tiles x%d, %s gather to rank 0%s" % (
                            world, "RCCL" if args.backend == "nccl" else "gloo (host-staged)",

@@ -88,7 +88,11 @@ typedef struct rt_stats {
     double   kernel_ms;      /* device time of the path-tracing kernel, HIP events  */
     double   total_ms;       /* wall time of the call                               */
     double   resolve_ms;     /* device time of the chunk-sum / gamma / RGBA8 kernel */
+    uint32_t chunk_spp;      /* samples per work unit used (the choice made for RT_CHUNK_AUTO) */
+    uint32_t reserved_;
 } rt_stats;
+
+enum { RT_CHUNK_AUTO = -1 };  /* rt_opts.chunk_spp: let the library choose the unit size */
 
 typedef struct rt_opts {
     int32_t  mode;           /* RT_MODE_*                                            */
@@ -99,7 +103,10 @@ typedef struct rt_opts {
     uint32_t sample_base;    /* index of the first sample (progressive frames pass
                                 frame*spp so that frames draw disjoint streams)      */
     int32_t  chunk_spp;      /* samples per work unit; a pixel's sum is the in-order
-                                sum of its chunks' in-order partial sums.  0 = spp   */
+                                sum of its chunks' in-order partial sums.  0 = spp
+                                (one unit per pixel: the reference's summation order,
+                                Main.c:973-976); RT_CHUNK_AUTO = chosen for throughput
+                                (a function of image size and spp only)              */
     int32_t  tile_rows;      /* multi-GPU row-tile height (0 = 16)                   */
     int32_t  part_index;     /* this call renders row tiles t with                   */
     int32_t  part_count;     /*   t % part_count == part_index  (0 or 1 = all rows)  */
@@ -140,7 +147,7 @@ int rt_set_world(const rt_sphere *spheres, size_t count);
  * `rgba` is caller-owned HOST memory, width*height*4 bytes, row 0 = top, alpha 255
  * (color4_t, include/util.h:227-233; BUF_AT, include/base_graphics.h:13).  With
  * opts->part_count > 1 only the owned rows are written, at their place in the
- * full image.  `opts` may be NULL (MC, fast kernel, seed 0, all rows). */
+ * full image.  `opts` may be NULL (MC, fast kernel, seed 0, all rows, RT_CHUNK_AUTO). */
 int rt_render(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height,
               int spp, int max_depth, const rt_opts *opts);
 

@@ -23,7 +23,7 @@ int main(int argc, char **argv)
     static rt_opts opts;
     opts.strict_fp = argc > 5 ? atoi(argv[5]) : 0;
     opts.seed = argc > 6 ? (uint32_t)strtoul(argv[6], NULL, 0) : 0;
-    opts.chunk_spp = argc > 7 ? atoi(argv[7]) : 0;
+    opts.chunk_spp = argc > 7 ? atoi(argv[7]) : RT_CHUNK_AUTO;
     g_dropin_opts = &opts;
 
     fast_srand(0);

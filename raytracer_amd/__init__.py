@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("RTMI_LIB", os.path.join(HERE, "librtmi.so"))   # RTMI
 CSRC = os.path.join(HERE, "csrc")
 
 MODE_MC, MODE_CONST_U = 0, 1
+CHUNK_AUTO = -1
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
 
 
@@ -41,7 +42,8 @@ class CameraParams(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("sphere_tests", C.c_uint64),
-                ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("resolve_ms", C.c_double)]
+                ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("resolve_ms", C.c_double),
+                ("chunk_spp", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 class Opts(C.Structure):

@@ -116,7 +116,9 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
     if (spp < 1) return fail(RT_ERR_ARG, "rt_render: spp must be >= 1 (got %d)", spp);
     if (max_depth < 0) return fail(RT_ERR_ARG, "rt_render: max_depth must be >= 0 (got %d)", max_depth);
     if (o.mode != RT_MODE_MC && o.mode != RT_MODE_CONST_U) return fail(RT_ERR_ARG, "rt_render: unknown mode %d", o.mode);
-    if (o.chunk_spp < 0 || o.tile_rows < 0) return fail(RT_ERR_ARG, "rt_render: negative chunk_spp or tile_rows");
+    const int chunk_opt = opts ? o.chunk_spp : RT_CHUNK_AUTO;
+    if ((chunk_opt < 0 && chunk_opt != RT_CHUNK_AUTO) || o.tile_rows < 0)
+        return fail(RT_ERR_ARG, "rt_render: negative chunk_spp or tile_rows");
     const int part_count = o.part_count > 1 ? o.part_count : 1;
     const int part_index = part_count > 1 ? o.part_index : 0;
     if (part_index < 0 || part_index >= part_count) return fail(RT_ERR_ARG, "rt_render: part_index %d outside [0,%d)", o.part_index, part_count);
@@ -133,12 +135,20 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
     }
     const uint32_t rows = explicit_rows ? o.row_count : rt_part_rows(height, tile_rows, part_index, part_count);
     const uint32_t npix = rows * width;
-    const int chunk = (o.chunk_spp > 0 && o.chunk_spp < spp) ? o.chunk_spp : spp;
+    const bool progressive = frame_index >= 0;
+    int chunk = (chunk_opt > 0 && chunk_opt < spp) ? chunk_opt : spp;
+    if (chunk_opt == RT_CHUNK_AUTO) {
+        // Short units keep the end of the launch, when units run out and lanes fall idle, short;
+        // below about 8 samples the per-unit work shows.  The per-chunk sums are capped at 2 GiB.
+        const uint64_t max_chunks = std::max<uint64_t>(1, (2ULL << 30) / (std::max<uint64_t>(npix, 1) * sizeof(float4)));
+        const uint64_t least = ((uint64_t)spp + max_chunks - 1) / max_chunks;
+        chunk = (int)std::min<uint64_t>((uint64_t)spp, std::max<uint64_t>(8, least));
+        if (progressive) while (spp % chunk != 0) chunk++;          // frames add whole chunks
+    }
     const int nchunks = (spp + chunk - 1) / chunk;
     const uint64_t units = (uint64_t)npix * (uint64_t)nchunks;
     if (units >= 0xffffffffULL) return fail(RT_ERR_ARG, "rt_render: %llu work units; raise chunk_spp", (unsigned long long)units);
 
-    const bool progressive = frame_index >= 0;
     uint32_t sample_base = o.sample_base;
     if (progressive) {
         if (max_depth < 1) return fail(RT_ERR_ARG, "rt_render_progressive: max_depth must be >= 1");
@@ -254,6 +264,7 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
 
     if (o.stats) {
         st.samples = (uint64_t)npix * (uint64_t)spp;
+        st.chunk_spp = (uint32_t)chunk;
         if (npix > 0 && max_depth > 0) {
             unsigned long long c[8] = {0};
             HIP_TRY(hipMemcpy(c, g.counters.p, sizeof c, hipMemcpyDeviceToHost));

@@ -22,6 +22,10 @@
 #error "RT_STRICT must be defined"
 #endif
 
+#ifndef RT_POOL_UNITS
+#define RT_POOL_UNITS 64
+#endif
+
 namespace rtmi {
 namespace RT_NS {
 
@@ -247,6 +251,7 @@ struct Diag { uint32_t branches, passes, drain_iters, drain_lanes, scans; };
 #endif
 
 constexpr int kQueueSlots = 16;            // per lane
+constexpr int kPoolUnits = RT_POOL_UNITS;  // work units a wave takes from the global counter at a time
 constexpr int kPairBatch = 4;              // pairs between two queue-overflow checks
 static_assert(kQueueLdsBytes == (kBlockThreads / 64) * kQueueSlots * 64 * 4, "host and kernel disagree on the queue size");
 static_assert(kGeomPad == 2 * kPairBatch, "the sphere list is padded to whole batches");
@@ -429,46 +434,57 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(cons
     bool need_unit = true;     // lane must pull a new work unit
     bool need_sample = true;   // lane must start a new sample
     uint32_t rays = 0;
+    uint32_t pool_next = 0, pool_end = 0;
 #ifdef RT_DIAG
     Diag dg = {0, 0, 0, 0, 0};
 #endif
 
     for (;;) {
-        // ---- pull work units: one atomic per wave ------------------------------------
+        // ---- pull work units ----------------------------------------------------------
+        // The wave keeps a pool of kPoolUnits consecutive units (wave-uniform registers) and
+        // hands them to the lanes that finished one; the one global counter is touched once
+        // per pool, not once per hand-out (8192 waves on one address saturate the atomic unit).
         unsigned long long want = __ballot(active && need_unit);
-        if (want != 0ULL) {
-            uint32_t cnt = (uint32_t)__popcll(want);
-            uint32_t base = 0;
-            if ((unsigned)__lane_id() == (unsigned)(__ffsll((long long)want) - 1))
-                base = (uint32_t)atomicAdd(&p.counters[0], (unsigned long long)cnt);
-            base = __shfl(base, __ffsll((long long)want) - 1);
-            if (active && need_unit) {
-                uint32_t rank = (uint32_t)__popcll(want & ((1ULL << __lane_id()) - 1ULL));
-                unsigned long long u64 = (unsigned long long)base + rank;
-                if (u64 >= (unsigned long long)total) {
-                    active = false;
-                } else {
-                    uint32_t u = (uint32_t)u64;
-#if RT_STRICT
-                    L.chunk = (int)(u / p.npix);
-                    L.pixc = u - (uint32_t)L.chunk * p.npix;
-                    uint32_t rowk = L.pixc / p.width;
-                    L.x = L.pixc - rowk * p.width;
-#else
-                    uint32_t chunk_u, rowk;
-                    divmod(u, p.npix, inv_npix, chunk_u, L.pixc);
-                    divmod(L.pixc, p.width, inv_width, rowk, L.x);
-                    L.chunk = (int)chunk_u;
-#endif
-                    L.y = p.rows ? p.rows[rowk] : part_row_at(rowk, p.tile_rows, p.part_index, p.part_count);
-                    L.pixhash = mix32((L.x + L.y * p.width) + mix32(p.seed ^ 0x6A09E667U));
-                    L.s = L.chunk * p.chunk_spp;
-                    int e = L.s + p.chunk_spp;
-                    L.s_end = e < p.spp ? e : p.spp;
-                    L.acc = v3(0.0f, 0.0f, 0.0f);
+        while (want != 0ULL) {
+            if (pool_next == pool_end) {
+                unsigned long long b64 = 0;
+                if (lane == 0) b64 = atomicAdd(&p.counters[0], (unsigned long long)kPoolUnits);
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b64 >> 32));
+                if (hi != 0U || lo >= total) {              // no units left: the waiting lanes retire
+                    if (need_unit) active = false;
+                    need_unit = false;
+                    break;
                 }
+                pool_next = lo;
+                pool_end = (total - lo < (uint32_t)kPoolUnits) ? total : lo + (uint32_t)kPoolUnits;
+            }
+            const uint32_t avail = pool_end - pool_next;
+            const uint32_t asked = (uint32_t)__popcll(want);
+            const uint32_t rank = (uint32_t)__popcll(want & ((1ULL << lane) - 1ULL));
+            if (active && need_unit && rank < avail) {
+                const uint32_t u = pool_next + rank;
+#if RT_STRICT
+                L.chunk = (int)(u / p.npix);
+                L.pixc = u - (uint32_t)L.chunk * p.npix;
+                uint32_t rowk = L.pixc / p.width;
+                L.x = L.pixc - rowk * p.width;
+#else
+                uint32_t chunk_u, rowk;
+                divmod(u, p.npix, inv_npix, chunk_u, L.pixc);
+                divmod(L.pixc, p.width, inv_width, rowk, L.x);
+                L.chunk = (int)chunk_u;
+#endif
+                L.y = p.rows ? p.rows[rowk] : part_row_at(rowk, p.tile_rows, p.part_index, p.part_count);
+                L.pixhash = mix32((L.x + L.y * p.width) + mix32(p.seed ^ 0x6A09E667U));
+                L.s = L.chunk * p.chunk_spp;
+                int e = L.s + p.chunk_spp;
+                L.s_end = e < p.spp ? e : p.spp;
+                L.acc = v3(0.0f, 0.0f, 0.0f);
                 need_unit = false;
             }
+            pool_next += asked < avail ? asked : avail;
+            want = __ballot(active && need_unit);
         }
         if (__ballot(active) == 0ULL) break;
 

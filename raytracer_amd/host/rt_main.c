@@ -59,6 +59,7 @@ int main(int argc, char **argv)
     memset(&o, 0, sizeof o);
     memset(&st, 0, sizeof st);
     o.stats = &st;
+    o.chunk_spp = RT_CHUNK_AUTO;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
         const char *v = (i + 1 < argc) ? argv[i + 1] : NULL;

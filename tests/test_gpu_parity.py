@@ -366,6 +366,25 @@ def test_scene_larger_than_the_lds_image(rt):
     assert psnr(f["rgba"], s["rgba"]) > 27.0
 
 
+@pytest.mark.parametrize("strict", [True, False])
+def test_auto_chunk(rt, strict):
+    """RT_CHUNK_AUTO: the library reports the unit size it chose, and the image is the one an
+    explicit request for that size gives (the choice depends on image size and spp only)."""
+    rt.set_world(load_scene("s3"))
+    W, H = 160, rt.height_for(160)
+    cam = rt.camera(W, H)
+    a = rt.render(cam, W, H, 40, 20, strict_fp=strict, seed=5, chunk_spp=rt.CHUNK_AUTO)
+    chosen = int(a["stats"].chunk_spp)
+    assert 1 <= chosen < 40
+    b = rt.render(cam, W, H, 40, 20, strict_fp=strict, seed=5, chunk_spp=chosen)
+    assert int(b["stats"].chunk_spp) == chosen
+    assert np.array_equal(a["rgba"], b["rgba"])
+    one = rt.render(cam, W, H, 40, 20, strict_fp=strict, seed=5, chunk_spp=0)
+    assert int(one["stats"].chunk_spp) == 40
+    f = rt.render_progressive(cam, W, H, 12, 20, 0, strict_fp=strict, seed=5, chunk_spp=rt.CHUNK_AUTO)
+    assert 12 % int(f["stats"].chunk_spp) == 0
+
+
 def test_explicit_row_lists_assemble_to_the_full_image(rt):
     """opts->rows: an arbitrary ascending row list per call (what a speed-weighted multi-GPU deal
     produces); host and device entries, compact device layout."""
