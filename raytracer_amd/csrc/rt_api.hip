@@ -139,10 +139,13 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
     int chunk = (chunk_opt > 0 && chunk_opt < spp) ? chunk_opt : spp;
     if (chunk_opt == RT_CHUNK_AUTO) {
         // Short units keep the end of the launch, when units run out and lanes fall idle, short;
-        // below about 8 samples the per-unit work shows.  The per-chunk sums are capped at 2 GiB.
+        // below about 8 samples the per-unit work shows, unless the launch is so small that a lane
+        // would see fewer than 32 units.  The per-chunk sums are capped at 2 GiB.
         const uint64_t max_chunks = std::max<uint64_t>(1, (2ULL << 30) / (std::max<uint64_t>(npix, 1) * sizeof(float4)));
         const uint64_t least = ((uint64_t)spp + max_chunks - 1) / max_chunks;
-        chunk = (int)std::min<uint64_t>((uint64_t)spp, std::max<uint64_t>(8, least));
+        const uint64_t lanes = (uint64_t)g.num_cu * 2048;
+        const uint64_t small = std::max<uint64_t>(1, (uint64_t)npix * (uint64_t)spp / (32 * lanes));
+        chunk = (int)std::min<uint64_t>((uint64_t)spp, std::max<uint64_t>(std::min<uint64_t>(8, small), least));
         if (progressive) while (spp % chunk != 0) chunk++;          // frames add whole chunks
     }
     const int nchunks = (spp + chunk - 1) / chunk;
@@ -200,6 +203,10 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
             tp.pairs = (const float *)g.pairs.p;
             tp.n = g.n; tp.n_pad = g.n_pad;
             tp.nbig = g.nbig; memcpy(tp.big, g.big, sizeof tp.big); tp.c_near = g.c_near;
+            // one ray over all spheres costs about 9 vector instructions per sphere pair in the scan (for
+            // all 64 lanes at once) and about 26 per 64 spheres plus a 6-step reduction when the
+            // lanes share one ray: the shared form wins while few rays are left in the wave
+            tp.coop_max = std::min(16, (int)((g.n_pad / 2 * 9 + 200) / (((g.n + 63) / 64) * 26 + 60)));
             tp.width = width; tp.height = height; tp.npix = npix;
             tp.tile_rows = tile_rows; tp.part_index = part_index; tp.part_count = part_count;
             tp.rows = nullptr;

@@ -43,6 +43,7 @@ struct TraceParams {
     int nbig;                              // spheres tested exactly for every ray
     int big[kMaxBig];
     float c_near;                          // max |C| over the filtered spheres
+    int coop_max;                          // a wave with at most this many live rays tests each ray with all 64 lanes
     uint32_t width, height;                // full image
     uint32_t npix;                         // owned pixels = owned_rows * width
     int tile_rows, part_index, part_count; // owned row k -> image row, see part_row_at()

@@ -328,6 +328,39 @@ __device__ __forceinline__ void scan_spheres(const TraceParams &p, const float4 
     drain(s_geom, queue, cnt, lane, q RT_DIAG_PASS);
 }
 
+// hit() for a wave in which only a few lanes still carry a ray (the end of a launch): the 64
+// lanes take one ray at a time, test 64 spheres per step with the exact test and reduce to the
+// nearest hit.  Same candidates, same test, same tie rule as the scan, hence the same result,
+// at 1/64 of the scan's latency per ray.
+__device__ __forceinline__ void shared_ray_hit(const TraceParams &p, const float4 *s_geom, int lane,
+                                               unsigned long long live, Probe &q)
+{
+    while (live != 0ULL) {
+        const int src = __ffsll((long long)live) - 1;
+        live &= live - 1ULL;
+        Probe t;
+        t.ox = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.ox), src));
+        t.oy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.oy), src));
+        t.oz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.oz), src));
+        t.dx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.dx), src));
+        t.dy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.dy), src));
+        t.dz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.dz), src));
+        t.tmin = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.tmin), src));
+#if RT_STRICT
+        t.a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.a), src));
+#endif
+        t.closest = 3.402823466e+38f;
+        t.hit = -1;
+        for (int i = lane; i < p.n; i += 64) exact_test(s_geom, i, t);
+        for (int off = 32; off > 0; off >>= 1) {
+            const float oc = __shfl_xor(t.closest, off);
+            const int oh = __shfl_xor(t.hit, off);
+            if (oc < t.closest || (oc == t.closest && oh < t.hit)) { t.closest = oc; t.hit = oh; }
+        }
+        if (lane == src) { q.closest = t.closest; q.hit = t.hit; }
+    }
+}
+
 struct Lane {
     // current ray (fast build: d is unit length and tmin carries the original length)
     V3 o, d;
@@ -512,7 +545,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(cons
             // discriminant h*h - a*c that decides in exact_test.
             q.a = q.dx * q.dx + q.dy * q.dy + q.dz * q.dz;
             const float inv = (q.a > 0.0f) ? __builtin_amdgcn_rsqf(q.a) : 0.0f;
-            scan_spheres(p, s_geom, queue, lane, q.dx * inv, q.dy * inv, q.dz * inv, 7.6293945e-6f, q RT_DIAG_PASS);
+            const unsigned long long live = __ballot(active);
+            if (__popcll(live) <= p.coop_max) shared_ray_hit(p, s_geom, lane, live, q);
+            else scan_spheres(p, s_geom, queue, lane, q.dx * inv, q.dy * inv, q.dz * inv, 7.6293945e-6f, q RT_DIAG_PASS);
             if (!(q.a > 0.0f)) {
                 // a zero or NaN direction gives the filter nothing to work with: test everything
                 q.closest = 3.402823466e+38f; q.hit = -1;
@@ -520,7 +555,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(cons
             }
         }
 #else
-        scan_spheres(p, s_geom, queue, lane, q.dx, q.dy, q.dz, 1.9073486e-6f, q RT_DIAG_PASS);   // 2^-19
+        const unsigned long long live = __ballot(active);
+        if (__popcll(live) <= p.coop_max) shared_ray_hit(p, s_geom, lane, live, q);
+        else scan_spheres(p, s_geom, queue, lane, q.dx, q.dy, q.dz, 1.9073486e-6f, q RT_DIAG_PASS);   // 2^-19
         if (L.zero_dir) q.hit = -1;
 #endif
         const float closest = q.closest;
