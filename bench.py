@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1000)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--chunk", type=int, default=-1, help="samples per work unit (-1: the library chooses)")
-    ap.add_argument("--tile-rows", type=int, default=16)
+    ap.add_argument("--tile-rows", type=int, default=2, help="rows per dealt tile: small tiles keep the deal fine-grained (2160 rows over 8 ranks)")
     ap.add_argument("--strict", type=int, default=0, help="1 = bit-reproducible build (no FMA)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-rebalance", action="store_true", help="keep the equal row-tile deal (N > 1)")
@@ -145,7 +145,9 @@ def main():
             speed = torch.zeros(world, dtype=torch.float64, device=coll_dev)
             speed[rank] = len(part.rows[rank]) / max(st.kernel_ms, 1e-6)
             dist.all_reduce(speed, op=dist.ReduceOp.SUM)
-            deal(speed.cpu().tolist())
+            sp = speed.cpu().numpy()
+            med = float(np.median(sp))
+            deal(np.clip(sp, 0.75 * med, 1.33 * med).tolist())        # one odd timing must not starve a rank
     sync()
     t0 = time.perf_counter()
     stats = [step() for _ in range(args.steps)]

@@ -42,30 +42,53 @@ class RowGather:
         self.counts = [len(r) for r in row_maps]
         self.max_rows = max(self.counts) if self.counts else 0
         height = sum(self.counts)
-        # every rank sends a buffer of the same shape: pad to the largest part
-        self.mine = torch.zeros((self.max_rows, width, channels), dtype=dtype, device=device)
+        # every rank sends a buffer of the same shape: pad to the largest part.  Two send buffers
+        # alternate, so that the frame being rendered never writes the rows a collective that is
+        # still in flight reads; an event per buffer marks the end of the collective that used it.
+        self._send = [torch.zeros((self.max_rows, width, channels), dtype=dtype, device=device) for _ in range(2)]
+        self._cur = 0
+        self._on_gpu = torch.device(device).type == "cuda"
+        self._done = [None, None]
         self.full = torch.zeros((height, width, channels), dtype=dtype, device=device) if rank == 0 else None
-        self.recv = ([torch.zeros_like(self.mine) for _ in range(world)]
+        self.recv = ([torch.zeros_like(self._send[0]) for _ in range(world)]
                      if (rank == 0 and world > 1) else None)
         self.idx = [torch.as_tensor(r, dtype=torch.int64, device=device) for r in row_maps] if rank == 0 else None
         if self.via_host and world > 1:
-            self.host_mine = torch.zeros(self.mine.shape, dtype=dtype)
+            self.host_mine = torch.zeros(self._send[0].shape, dtype=dtype)
             self.host_recv = [torch.zeros_like(self.host_mine) for _ in range(world)] if rank == 0 else None
 
+    @property
+    def mine(self):
+        """This rank's send buffer for the next gather() (compact rows, padded)."""
+        ev = self._done[self._cur]
+        if ev is not None:
+            ev.synchronize()                   # the collective that last read this buffer has finished
+            self._done[self._cur] = None
+        return self._send[self._cur]
+
     def gather(self):
-        """Collect self.mine from all ranks into self.full on rank 0."""
+        """Collect self.mine from all ranks into self.full on rank 0; then switch send buffers."""
+        full = self._gather(self._send[self._cur])
+        if self._on_gpu:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._done[self._cur] = ev
+        self._cur ^= 1
+        return full
+
+    def _gather(self, mine):
         if self.world > 1:
             if self.via_host:
-                self.host_mine.copy_(self.mine)
+                self.host_mine.copy_(mine)
                 dist.gather(self.host_mine, self.host_recv, dst=0)
                 if self.rank == 0:
                     for i in range(self.world):
                         self.recv[i].copy_(self.host_recv[i])
             else:
-                dist.gather(self.mine, self.recv, dst=0)
+                dist.gather(mine, self.recv, dst=0)
             if self.rank == 0:
                 for i in range(self.world):
                     self.full.index_copy_(0, self.idx[i], self.recv[i][:self.counts[i]])
         else:
-            self.full.index_copy_(0, self.idx[0], self.mine[:self.counts[0]])
+            self.full.index_copy_(0, self.idx[0], mine[:self.counts[0]])
         return self.full
