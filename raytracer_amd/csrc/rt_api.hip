@@ -223,7 +223,7 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
             tp.total_units = units;
 
             const bool geom_global = g.n > kMaxSpheresLds;
-            const size_t lds = (geom_global ? 0 : (size_t)g.n_pad * sizeof(float4)) + kQueueLdsBytes;
+            const size_t lds = (geom_global ? 0 : (size_t)g.n_pad * sizeof(float4)) + (size_t)queue_lds_bytes(kBlockThreads, o.strict_fp ? kQueueSlotsStrict : kQueueSlotsFast);
             const int per_cu = o.strict_fp ? trace_blocks_per_cu_strict(geom_global, lds) : trace_blocks_per_cu_fast(geom_global, lds);
             uint64_t blocks = (uint64_t)g.num_cu * (uint64_t)per_cu;
             const uint64_t need = (units + kBlockThreads - 1) / kBlockThreads;

@@ -23,10 +23,15 @@ constexpr int kGeomPad = 8;
 // larger than the rest (the r = 1000 ground) would inflate that bound for every sphere, so they
 // are kept out of the filter (k = +inf) and tested exactly for every ray: big[] lists them.
 constexpr int kMaxBig = 16;
-constexpr int kQueueLdsBytes = (512 / 64) * 16 * 64 * 4;   // per workgroup: 8 waves x 16 slots x 64 lanes x u32
-constexpr int kMaxSpheresLds = 2048;       // up to here the per-sphere records are staged in LDS (<= 96 KB + 32 KB of queues)
+// Workgroups of 4 waves, one per SIMD.  The fast build fits 72 VGPRs, i.e. 7 waves per SIMD (8
+// would need 64 VGPRs and spill): 7 workgroups per CU, whose LDS (geometry image + queues) fits
+// 160 KB with 12 queue slots per lane.  The strict build needs more registers (6 waves per SIMD).
+constexpr int kBlockThreads = 256;
+constexpr int kQueueSlotsFast = 12;        // candidate-queue slots per lane
+constexpr int kQueueSlotsStrict = 16;
+constexpr int queue_lds_bytes(int block_threads, int slots) { return (block_threads / 64) * slots * 64 * 4; }   // waves x slots x 64 lanes x u32
+constexpr int kMaxSpheresLds = 2048;       // up to here the per-sphere records are staged in LDS (<= 32 KB + 16 KB of queues per workgroup)
 constexpr int kMaxSpheres = 1 << 20;       // beyond kMaxSpheresLds they are read from global memory
-constexpr int kBlockThreads = 512;         // 8 waves per workgroup
 
 struct Camera {                            // rt_camera, flattened
     float pos[3], p00[3], du[3], dv[3], ddu[3], ddv[3];

@@ -250,10 +250,10 @@ struct Diag { uint32_t branches, passes, drain_iters, drain_lanes, scans; };
 #define RT_DIAG_PASS
 #endif
 
-constexpr int kQueueSlots = 16;            // per lane
+constexpr int kQueueSlots = RT_STRICT ? kQueueSlotsStrict : kQueueSlotsFast;   // per lane
 constexpr int kPoolUnits = RT_POOL_UNITS;  // work units a wave takes from the global counter at a time
 constexpr int kPairBatch = 4;              // pairs between two queue-overflow checks
-static_assert(kQueueLdsBytes == (kBlockThreads / 64) * kQueueSlots * 64 * 4, "host and kernel disagree on the queue size");
+static_assert(kQueueSlots > 2 * kPairBatch, "a batch of pairs must fit the queue");
 static_assert(kGeomPad == 2 * kPairBatch, "the sphere list is padded to whole batches");
 
 // Exact test of the queued candidates of every lane of the wave; queue[j * 64 + lane] is the
