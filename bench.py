@@ -189,10 +189,12 @@ def main():
                        "rows_per_rank": [int(len(r)) for r in part.rows]},
             "roofline": {"bound": "valu_fp32", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-                         # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this
-                         # command (profiles/r1b_filter_scan/hbm_traffic.json); only meaningful for the
-                         # default workload on one GPU, null otherwise
-                         "traffic": (9.11e9 if (world == 1 and W == 3840 and args.spp == 1000 and args.chunk == 50) else None),
+                         # HBM bytes per launch of trace_kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+                         # passes on this command (profiles/r1d_unit_pool/pmc_fetch.csv, pmc_write.csv;
+                         # FETCH_SIZE doubled, the gfx950 correction): 2.22 GB written + 0.20 GB read.
+                         # Only known for the default workload on one GPU, null otherwise
+                         "traffic": (2.42e9 if (world == 1 and W == 3840 and args.spp == 1000
+                                                and int(stats[-1].chunk_spp) == 63 and not args.strict) else None),
                          "kernel": "trace_kernel", "kernel_ms": round(kernel_ms, 3),
                          "flop_per_sphere_test": FLOP_PER_TEST,
                          "sphere_tests_per_launch": tests, "rays_per_sample": round(rays / own_samples, 4)},

@@ -27,10 +27,10 @@ constexpr int kMaxBig = 16;
 // would need 64 VGPRs and spill): 7 workgroups per CU, whose LDS (geometry image + queues) fits
 // 160 KB with 12 queue slots per lane.  The strict build needs more registers (6 waves per SIMD).
 constexpr int kBlockThreads = 256;
-constexpr int kQueueSlotsFast = 12;        // candidate-queue slots per lane
+constexpr int kQueueSlotsFast = 14;        // candidate-queue slots per lane
 constexpr int kQueueSlotsStrict = 16;
 constexpr int queue_lds_bytes(int block_threads, int slots) { return (block_threads / 64) * slots * 64 * 4; }   // waves x slots x 64 lanes x u32
-constexpr int kMaxSpheresLds = 2048;       // up to here the per-sphere records are staged in LDS (<= 32 KB + 16 KB of queues per workgroup)
+constexpr int kMaxSpheresLds = 560;        // up to here the per-sphere records are staged in LDS: 7 workgroups of (9 KB + 14 KB of queues) still fit a CU
 constexpr int kMaxSpheres = 1 << 20;       // beyond kMaxSpheresLds they are read from global memory
 
 struct Camera {                            // rt_camera, flattened

@@ -10,7 +10,10 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 strict = bool(int(sys.argv[4])) if len(sys.argv) > 4 else False
 scene = sys.argv[5] if len(sys.argv) > 5 else "sf"
 chunk = int(os.environ.get("RT_CHUNK", "50"))
-sph = np.fromfile(os.path.join(ROOT, "tests", "golden", "scene_%s.bin" % scene), dtype=rt.SPHERE_DTYPE)
+if scene.startswith("gen"):        # genN: rt_scene_generate with half extent N
+    sph = rt.scene_generate(int(scene[3:]), 0)
+else:
+    sph = np.fromfile(os.path.join(ROOT, "tests", "golden", "scene_%s.bin" % scene), dtype=rt.SPHERE_DTYPE)
 rt.init(0)
 rt.set_world(sph)
 h = rt.height_for(w)
@@ -18,7 +21,7 @@ cam = rt.camera(w, h)
 buf = np.zeros((h, w, 4), np.uint8)
 for r in range(reps):
     st = rt.render(cam, w, h, spp, 50, strict_fp=strict, chunk_spp=chunk, out=buf)['stats']
-    print("%s %dx%d spp %d: kernel %.2f ms  %.1f Msamples/s  frac %.4f  rays/sample %.3f" % (
-        "strict" if strict else "fast", w, h, spp, st.kernel_ms, st.samples / st.kernel_ms / 1e3,
+    print("%s n=%d %dx%d spp %d: kernel %.2f ms  %.1f Msamples/s  frac %.4f  rays/sample %.3f" % (
+        "strict" if strict else "fast", len(sph), w, h, spp, st.kernel_ms, st.samples / st.kernel_ms / 1e3,
         18.0 * st.sphere_tests / (st.kernel_ms * 1e-3) / 157.3e12, st.rays / st.samples), flush=True)
 rt.shutdown()
