@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Headline benchmark: Msamples/s (pixels x spp per second) on the RTIOW final scene,
-3840x2160, 1000 spp, depth 50 (BASELINE.json configs[3]), on 1..8 MI355X.
+3840x2160, 1000 spp, depth 50 (the largest configuration the metric is quoted on), on 1..8 MI355X.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -190,7 +190,7 @@ def main():
             "roofline": {"bound": "valu_fp32", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
                          # HBM bytes per launch of trace_kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-                         # passes on this command (profiles/r1d_unit_pool/pmc_fetch.csv, pmc_write.csv;
+                         # passes on this command (the counter files are kept under profiles/;
                          # FETCH_SIZE doubled, the gfx950 correction): 2.22 GB written + 0.20 GB read.
                          # Only known for the default workload on one GPU, null otherwise
                          "traffic": (2.42e9 if (world == 1 and W == 3840 and args.spp == 1000

@@ -46,7 +46,7 @@ def main():
     for s in ("s3", "sf"):
         run(s, "scene", 400, 1, 1).tofile(os.path.join(GOLD, "scene_%s.bin" % s))
 
-    # glass-heavy scene "SG" (BASELINE config 5): the reference holds no definition of it (only a
+    # glass-heavy scene "SG" (the 1 spp/frame progressive configuration): the reference holds no definition of it (only a
     # screenshot), so it is DEFINED here: the final scene with every r = 0.2 sphere turned into
     # glass (Dielectric, ior 1.5); viewed from pos (9, 7, 3) looking at the origin.
     sf = np.fromfile(os.path.join(GOLD, "scene_sf.bin"), dtype=np.uint8).reshape(-1, 40).copy()
@@ -56,7 +56,7 @@ def main():
     rec[small, 9] = 1.5
     sf.tofile(os.path.join(GOLD, "scene_sg.bin"))
 
-    # cameras at the BASELINE widths (init_camera + update_camera_view, Main.c:839-928)
+    # cameras at the benchmark widths (init_camera + update_camera_view, Main.c:839-928)
     cams = {}
     for w in (100, 400, 1200, 1920, 3840):
         raw = run("s3", "camera", w, 1, 1)

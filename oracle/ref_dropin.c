@@ -34,7 +34,7 @@ int main(int argc, char **argv)
     gc.frame_arena = arena_new();                             /* Main.c:1375 */
     gc.font = init_font((u32 *)font_pixels);                  /* Main.c:1381 */
 
-    /* the binding INTEGRATION.md describes: flatten gc.scene_objects into rt_sphere records */
+    /* the binding a maintainer adds after init_scene: flatten gc.scene_objects into rt_sphere records */
     size_t n = gc.scene_objects->count;
     rt_sphere *tmp = calloc(n ? n : 1, sizeof *tmp);
     for (size_t i = 0; i < n; i++) {

@@ -81,14 +81,14 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
     return x;
 }
 
-struct Rng { uint32_t key, n; };
+struct Rng { uint32_t ctr; };          // key + n * 0x9E3779B9 of the next draw
 
 template <int MODE>
 __device__ __forceinline__ float rng_float(Rng &r)
 {
     if (MODE == 1) return 0.5f;                       // RT_MODE_CONST_U: fast_rand() == 16384
-    uint32_t x = mix32(r.key + r.n * 0x9E3779B9U);
-    r.n++;
+    uint32_t x = mix32(r.ctr);
+    r.ctr += 0x9E3779B9U;
     return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
 
@@ -154,8 +154,8 @@ template <int MODE>
 __device__ __forceinline__ void rng_float2(Rng &r, float &u0, float &u1)
 {
     if (MODE == 1) { u0 = 0.5f; u1 = 0.5f; return; }
-    const uint32_t x = mix32(r.key + r.n * 0x9E3779B9U);
-    r.n++;
+    const uint32_t x = mix32(r.ctr);
+    r.ctr += 0x9E3779B9U;
     u0 = (float)(x >> 16) * (1.0f / 65536.0f);
     u1 = (float)(x & 0xffffu) * (1.0f / 65536.0f);
 }
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(cons
     L.d = v3(0.0f, 0.0f, 1.0f);
     L.tmin = 0.001f;
     L.zero_dir = false;
-    L.rng.key = 0; L.rng.n = 0; L.pixhash = 0;
+    L.rng.ctr = 0; L.pixhash = 0;
     L.pixc = 0; L.x = 0; L.y = 0; L.s = 0; L.s_end = 0; L.chunk = 0; L.bounce = 0;
     bool active = true;        // lane still has (or may get) work
     bool need_unit = true;     // lane must pull a new work unit
@@ -523,8 +523,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(cons
 
         // ---- start a new sample where the previous path ended ------------------------
         if (active && need_sample) {
-            L.rng.key = mix32(L.pixhash ^ ((p.sample_base + (uint32_t)L.s) * 0x9E3779B9U));
-            L.rng.n = 0;
+            L.rng.ctr = mix32(L.pixhash ^ ((p.sample_base + (uint32_t)L.s) * 0x9E3779B9U));
             camera_ray<MODE>(p, L);
             L.thr = v3(1.0f, 1.0f, 1.0f);
             L.bounce = 0;

@@ -18,7 +18,7 @@ from oracle import refcpu as rc
 
 pytestmark = pytest.mark.gpu
 
-PSNR_BAR_DB = 40.0      # BASELINE.json north_star: ">= 40 dB PSNR against the reference's own render"
+PSNR_BAR_DB = 40.0      # the acceptance bar: ">= 40 dB PSNR against the reference's own render"
 
 
 def bits(a):

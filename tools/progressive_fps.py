@@ -1,5 +1,5 @@
 """Frames per second of progressive 1-spp accumulation with read-back into host memory
-(BASELINE config 5 without the GLFW window): python tools/progressive_fps.py [width] [frames] [scene]"""
+(the glass-heavy 1 spp/frame configuration, without the GLFW window): python tools/progressive_fps.py [width] [frames] [scene]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
