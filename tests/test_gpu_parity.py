@@ -366,6 +366,56 @@ def test_scene_larger_than_the_lds_image(rt):
     assert psnr(f["rgba"], s["rgba"]) > 27.0
 
 
+def _tie_scene(n, seed):
+    """Random spheres with everything hit()'s tie and range rules care about: exact duplicates and
+    concentric equal spheres (equal t: the lower index must win), touching spheres, a zero radius,
+    spheres around the camera, mirror metal, glass of index below and above 1."""
+    r = np.random.default_rng(seed)
+    s = np.zeros(n, dtype=rc.SPHERE_DTYPE)
+    s["center"] = r.uniform(-4, 4, (n, 3))
+    s["radius"] = r.uniform(0.1, 1.2, n)
+    s["mat_type"] = r.integers(0, 3, n)
+    s["albedo"] = r.uniform(0.1, 1.0, (n, 3))
+    s["fuzz"] = np.where(r.random(n) < 0.5, 0.0, r.uniform(0, 1.0, n))
+    s["ior"] = np.where(r.random(n) < 0.3, 0.7, 1.5)
+    for k in range(1, n, 5):                 # duplicates of an earlier sphere, other material
+        s["center"][k] = s["center"][k - 1]
+        s["radius"][k] = s["radius"][k - 1]
+    if n > 6:
+        s["radius"][3] = 0.0
+        s["center"][4] = (9.0, 1.0, 2.0)     # around the camera of _tie_camera
+        s["radius"][4] = 1.5
+        s["mat_type"][4] = 2
+        s["center"][6] = s["center"][5] + np.array([s["radius"][5] + 0.5, 0, 0], np.float32)
+        s["radius"][6] = 0.5                 # touches sphere 5
+    return s
+
+
+@pytest.mark.parametrize("n,seed", [(1, 0), (2, 1), (7, 2), (65, 3), (130, 4), (257, 5), (600, 6), (1100, 7)])
+def test_strict_build_matches_checker_on_random_scenes(rt, n, seed):
+    """Bit-exact parity away from the two shipped scenes, through both geometry paths (LDS image up
+    to 560 spheres, global memory beyond): hit indices, accumulators, bytes and ray counts."""
+    sph = _tie_scene(n, seed)
+    rt.set_world(sph)
+    p = rt.default_params()
+    p.pos = rt.Vec3(9.0, 1.0, 2.0)
+    p.target = rt.Vec3(0.0, 0.0, 0.0)
+    p.vfov = 68.4                            # tan_f32 takes turns (util.h:134,142): half-height tan(pi * 1.194) = 0.70
+    W, H = 128, 72
+    cam = rt.camera(W, H, p)
+    ccam = rc.Camera.from_buffer_copy(bytes(cam))
+    for mode, rng in ((rt.MODE_CONST_U, rc.RNG_CONST_U), (rt.MODE_MC, rc.RNG_COUNTER)):
+        r = rt.render(cam, W, H, 3, 12, mode=mode, strict_fp=True, seed=40 + seed, chunk_spp=2,
+                      want_hit=True, want_accum=True)
+        c = rc.render(ccam, sph, W, H, 3, 12, rng=rng, seed=40 + seed, chunk_spp=2, want_hit=True, want_accum=True)
+        assert np.array_equal(r["hit"], c["hit"])
+        assert np.array_equal(r["accum"].view(np.uint32), c["accum"].view(np.uint32))
+        assert np.array_equal(r["rgba"], c["rgba"])
+        assert int(r["stats"].rays) == int(c["stats"].rays)
+    if n >= 65:
+        assert (r["hit"] >= 0).mean() > 0.2                  # the view does see the scene
+
+
 @pytest.mark.parametrize("strict", [True, False])
 def test_auto_chunk(rt, strict):
     """RT_CHUNK_AUTO: the library reports the unit size it chose, and the image is the one an
