@@ -136,6 +136,17 @@ enum rt_status {
  * OS threads per tile, Main.c:1002-1045). */
 int rt_init(int device);
 
+/* Same for `count` devices (1..16) in ONE process: the reference is a single-process program
+ * (one GLFW thread, Main.c:1440-1443), so this is how its frame loop reaches several GPUs
+ * without a launcher.  rt_set_world uploads to every device; rt_render deals the rows it owns to
+ * the devices in 2-row tiles, in proportion to the speed each device showed in the previous
+ * frame, renders them concurrently (one host thread per device) and writes every row at its
+ * place in the caller's buffers; rt_stats then holds sums (samples, rays, sphere_tests) and
+ * maxima (kernel_ms, resolve_ms).  The image is the single-device image, byte for byte.
+ * rt_render_device and rt_render_progressive need a single device (RT_ERR_STATE otherwise).
+ * An id may be listed more than once (contexts sharing a device; used by the tests). */
+int rt_init_devices(const int *devices, int count);
+
 /* Replaces gc.scene_objects (Main.c:116, filled by init_scene, Main.c:1212-1318).
  * `spheres` is copied; only RT_MAT_LAMBERTIAN/METAL/DIELECTRIC are accepted (the
  * reference's Emissive case leaves the scattered ray uninitialised, Main.c:613-619). */
@@ -199,7 +210,7 @@ int rt_scene_generate(int half_extent, uint32_t lcg_seed, rt_sphere *out, size_t
 /* Frees everything rt_init / rt_set_world created. */
 void rt_shutdown(void);
 
-/* Text of the last error reported to this process ("" if none). */
+/* Text of the last error reported to the calling thread ("" if none). */
 const char *rt_last_error(void);
 
 #ifdef __cplusplus

@@ -59,7 +59,7 @@ SPHERE_DTYPE = np.dtype([("center", "<f4", 3), ("radius", "<f4"), ("mat_type", "
                          ("albedo", "<f4", 3), ("fuzz", "<f4"), ("ior", "<f4")])
 assert SPHERE_DTYPE.itemsize == 40
 
-EXPORTS = ["rt_init", "rt_set_world", "rt_render", "rt_render_device", "rt_render_progressive", "rt_part_rows",
+EXPORTS = ["rt_init", "rt_init_devices", "rt_set_world", "rt_render", "rt_render_device", "rt_render_progressive", "rt_part_rows",
            "rt_part_row_at", "rt_camera_setup", "rt_camera_defaults", "rt_height_for",
            "rt_scene_generate", "rt_shutdown", "rt_last_error"]
 
@@ -83,6 +83,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.rt_init.restype = C.c_int
         L.rt_init.argtypes = [C.c_int]
+        L.rt_init_devices.restype = C.c_int
+        L.rt_init_devices.argtypes = [C.POINTER(C.c_int), C.c_int]
         L.rt_set_world.restype = C.c_int
         L.rt_set_world.argtypes = [C.c_void_p, C.c_size_t]
         for f in (L.rt_render, L.rt_render_device):
@@ -117,6 +119,12 @@ def _check(rc, what):
 
 def init(device=0):
     _check(lib().rt_init(device), "rt_init")
+
+
+def init_devices(devices):
+    """rt_init_devices: several GPUs in this one process (rt_render splits the rows among them)."""
+    arr = (C.c_int * len(devices))(*devices)
+    _check(lib().rt_init_devices(arr, len(devices)), "rt_init_devices")
 
 
 def shutdown():

@@ -1,6 +1,8 @@
 // Host side of librtmi.so: the extern "C" entry points declared in include/rt.h.
-// Owns the HIP device, one stream, the structure-of-arrays world and the scratch buffers
-// (per-chunk partial sums, work/ray counters, staging for host-pointer callers).
+// Owns one context per device given to rt_init / rt_init_devices (stream, events, the
+// structure-of-arrays world, scratch: per-chunk partial sums, work/ray counters, staging for
+// host-pointer callers).  With several contexts rt_render deals the image rows to them and runs
+// one host thread per context.
 #include "../../include/rt.h"
 #include "rt_device.h"
 
@@ -12,6 +14,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <string>
+#include <thread>
 #include <vector>
 
 #pragma clang fp contract(off)
@@ -37,10 +41,14 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-struct State {
+constexpr int kMaxContexts = 16;
+
+struct Ctx {
     bool inited = false;
     int device = -1;
     int num_cu = 0;
+    LaunchCache launch;
+    double speed = 1.0;          // rows per kernel-millisecond of the last multi-context frame (weight of the next deal)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     // world
@@ -58,9 +66,12 @@ struct State {
     std::vector<uint8_t> h_rgba;
     std::vector<float> h_accum;
     std::vector<int32_t> h_hit;
-} g;
+};
 
-char g_err[512] = "";
+Ctx g_ctx[kMaxContexts];
+int g_nctx = 0;
+
+thread_local char g_err[512] = "";      // per thread: the worker threads of a multi-device frame report through it
 
 int fail(int code, const char *fmt, ...)
 {
@@ -99,7 +110,7 @@ inline rt_vec3 R(V3 a) { rt_vec3 r; r.x = a.x; r.y = a.y; r.z = a.z; return r; }
 inline float turns_to_rad(float v) { return v * (2 * 3.1415926535897f); }
 inline float deg_to_rad(float v) { return turns_to_rad(v / 360.f); }
 
-int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height, int spp,
+int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height, int spp,
                   int max_depth, const rt_opts *opts, bool device_ptrs, int64_t frame_index = -1)
 {
     using clk = std::chrono::steady_clock;
@@ -224,14 +235,14 @@ int render_common(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
 
             const bool geom_global = g.n > kMaxSpheresLds;
             const size_t lds = (geom_global ? 0 : (size_t)g.n_pad * sizeof(float4)) + (size_t)queue_lds_bytes(kBlockThreads, o.strict_fp ? kQueueSlotsStrict : kQueueSlotsFast);
-            const int per_cu = o.strict_fp ? trace_blocks_per_cu_strict(geom_global, lds) : trace_blocks_per_cu_fast(geom_global, lds);
+            const int per_cu = o.strict_fp ? trace_blocks_per_cu_strict(g.launch, geom_global, lds) : trace_blocks_per_cu_fast(g.launch, geom_global, lds);
             uint64_t blocks = (uint64_t)g.num_cu * (uint64_t)per_cu;
             const uint64_t need = (units + kBlockThreads - 1) / kBlockThreads;
             if (blocks > need) blocks = need;
 
             HIP_TRY(hipEventRecord(g.ev0, g.stream));
-            HIP_TRY(o.strict_fp ? launch_trace_strict(tp, geom_global, (int)blocks, lds, g.stream)
-                                : launch_trace_fast(tp, geom_global, (int)blocks, lds, g.stream));
+            HIP_TRY(o.strict_fp ? launch_trace_strict(g.launch, tp, geom_global, (int)blocks, lds, g.stream)
+                                : launch_trace_fast(g.launch, tp, geom_global, (int)blocks, lds, g.stream));
             HIP_TRY(hipEventRecord(g.ev1, g.stream));
             ResolveParams rp;
             rp.partial = (const float4 *)g.partial.p; rp.nchunks = nchunks; rp.npix = npix;
@@ -300,12 +311,22 @@ extern "C" {
 
 const char *rt_last_error(void) { return g_err; }
 
-int rt_init(int device)
+static void release_ctx(Ctx &g)
 {
-    if (g.inited) rt_shutdown();
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count <= 0) return fail(RT_ERR_DEVICE, "rt_init: no HIP device (%s)", hipGetErrorString(e));
+    if (!g.inited) return;
+    (void)hipSetDevice(g.device);
+    if (g.stream) (void)hipStreamSynchronize(g.stream);
+    g.geom.release(); g.matA.release(); g.matB.release(); g.pairs.release();
+    g.partial.release(); g.running.release(); g.rows.release(); g.counters.release(); g.rgba.release(); g.accum.release(); g.hit.release();
+    if (g.ev0) (void)hipEventDestroy(g.ev0);
+    if (g.ev1) (void)hipEventDestroy(g.ev1);
+    if (g.ev2) (void)hipEventDestroy(g.ev2);
+    if (g.stream) (void)hipStreamDestroy(g.stream);
+    g = Ctx();
+}
+
+static int init_ctx(Ctx &g, int device, int count)
+{
     if (device < 0 || device >= count) return fail(RT_ERR_ARG, "rt_init: device %d outside [0,%d)", device, count);
     HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
@@ -314,26 +335,46 @@ int rt_init(int device)
         return fail(RT_ERR_DEVICE, "rt_init: device %d is %s; this library holds gfx950 code only", device, prop.gcnArchName);
     g.device = device;
     g.num_cu = prop.multiProcessorCount;
+    g.inited = true;                      // from here on release_ctx cleans up
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&g.ev0));
     HIP_TRY(hipEventCreate(&g.ev1));
     HIP_TRY(hipEventCreate(&g.ev2));
     HIP_TRY(g.counters.reserve(8 * sizeof(unsigned long long)));
-    g.inited = true;
+    return RT_OK;
+}
+
+int rt_init_devices(const int *devices, int count)
+{
+    rt_shutdown();
+    if (!devices || count < 1 || count > kMaxContexts)
+        return fail(RT_ERR_ARG, "rt_init_devices: between 1 and %d devices (got %d)", kMaxContexts, count);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(RT_ERR_DEVICE, "rt_init: no HIP device (%s)", hipGetErrorString(e));
+    for (int i = 0; i < count; i++) {
+        const int rc = init_ctx(g_ctx[i], devices[i], ndev);
+        if (rc != RT_OK) {
+            for (int k = 0; k <= i; k++) release_ctx(g_ctx[k]);
+            return rc;
+        }
+    }
+    g_nctx = count;
     g_err[0] = 0;
     return RT_OK;
 }
 
+int rt_init(int device) { return rt_init_devices(&device, 1); }
+
 int rt_set_world(const rt_sphere *spheres, size_t count)
 {
-    if (!g.inited) return fail(RT_ERR_STATE, "rt_set_world: rt_init has not been called");
+    if (g_nctx == 0) return fail(RT_ERR_STATE, "rt_set_world: rt_init has not been called");
     if (!spheres && count) return fail(RT_ERR_ARG, "rt_set_world: null sphere array");
     if (count > (size_t)kMaxSpheres)
         return fail(RT_ERR_ARG, "rt_set_world: %zu spheres; at most %d are supported", count, kMaxSpheres);
     for (size_t i = 0; i < count; i++)
         if (spheres[i].mat_type < RT_MAT_LAMBERTIAN || spheres[i].mat_type > RT_MAT_DIELECTRIC)
             return fail(RT_ERR_ARG, "rt_set_world: sphere %zu has unsupported material type %d", i, spheres[i].mat_type);
-    HIP_TRY(hipSetDevice(g.device));
     const int n = (int)count;
     const int n_pad = n == 0 ? kGeomPad : ((n + kGeomPad - 1) / kGeomPad) * kGeomPad;
     std::vector<float4> geom(n_pad), matA(n > 0 ? n : 1), matB(n > 0 ? n : 1);
@@ -383,38 +424,130 @@ int rt_set_world(const rt_sphere *spheres, size_t count)
             q[0] = 0.0f; q[2] = 0.0f; q[4] = 0.0f; q[6] = inf;       // never passes the filter
         }
     }
-    HIP_TRY(g.pairs.reserve(pairs.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(g.pairs.p, pairs.data(), pairs.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(g.geom.reserve(geom.size() * sizeof(float4)));
-    HIP_TRY(g.matA.reserve(matA.size() * sizeof(float4)));
-    HIP_TRY(g.matB.reserve(matB.size() * sizeof(float4)));
-    HIP_TRY(hipMemcpy(g.geom.p, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(g.matA.p, matA.data(), matA.size() * sizeof(float4), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(g.matB.p, matB.data(), matB.size() * sizeof(float4), hipMemcpyHostToDevice));
-    g.n = n;
-    g.n_pad = n_pad;
-    g.nbig = nbig;
-    memcpy(g.big, big, sizeof big);
-    g.c_near = (float)c_near;
+    for (int k = 0; k < g_nctx; k++) {
+        Ctx &g = g_ctx[k];
+        HIP_TRY(hipSetDevice(g.device));
+        HIP_TRY(g.pairs.reserve(pairs.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(g.pairs.p, pairs.data(), pairs.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(g.geom.reserve(geom.size() * sizeof(float4)));
+        HIP_TRY(g.matA.reserve(matA.size() * sizeof(float4)));
+        HIP_TRY(g.matB.reserve(matB.size() * sizeof(float4)));
+        HIP_TRY(hipMemcpy(g.geom.p, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(g.matA.p, matA.data(), matA.size() * sizeof(float4), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(g.matB.p, matB.data(), matB.size() * sizeof(float4), hipMemcpyHostToDevice));
+        g.n = n;
+        g.n_pad = n_pad;
+        g.nbig = nbig;
+        memcpy(g.big, big, sizeof big);
+        g.c_near = (float)c_near;
+    }
+    return RT_OK;
+}
+
+// Several contexts: the rows this call owns (all rows, the caller's part, or the caller's row list)
+// are dealt in tiles to the contexts in proportion to the speed each showed in the previous frame
+// (smooth weighted round robin: every context's tiles stay spread over the image), one host thread
+// per context renders its rows into the caller's buffers.  The image does not depend on the deal.
+static int render_on_all(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height, int spp,
+                         int max_depth, const rt_opts *opts)
+{
+    using clk = std::chrono::steady_clock;
+    const auto t_start = clk::now();
+    rt_opts base;
+    memset(&base, 0, sizeof base);
+    if (opts) base = *opts; else base.chunk_spp = RT_CHUNK_AUTO;
+    if (height == 0 || width == 0) return fail(RT_ERR_ARG, "rt_render: bad image size %ux%u", width, height);
+    const int tile_rows = base.tile_rows > 0 ? base.tile_rows : 16;
+    const int part_count = base.part_count > 1 ? base.part_count : 1;
+    const int part_index = part_count > 1 ? base.part_index : 0;
+    if (part_index < 0 || part_index >= part_count) return fail(RT_ERR_ARG, "rt_render: part_index %d outside [0,%d)", base.part_index, part_count);
+    std::vector<uint32_t> mine;
+    if (base.rows) {
+        for (uint32_t k = 0; k < base.row_count; k++) {
+            if (base.rows[k] >= height || (k > 0 && base.rows[k] <= base.rows[k - 1]))
+                return fail(RT_ERR_ARG, "rt_render: rows[] must be strictly ascending and below the image height (entry %u)", k);
+            mine.push_back(base.rows[k]);
+        }
+    } else {
+        const uint32_t n = rt_part_rows(height, tile_rows, part_index, part_count);
+        for (uint32_t k = 0; k < n; k++) mine.push_back(rt_part_row_at(k, tile_rows, part_index, part_count));
+    }
+    const int nc = g_nctx;
+    double wsum = 0.0;
+    for (int i = 0; i < nc; i++) wsum += g_ctx[i].speed;
+    std::vector<double> credit(nc, 0.0);
+    std::vector<std::vector<uint32_t>> rows(nc);
+    const int deal_rows = 2;                                  // fine tiles: the split follows the weights closely
+    for (size_t t = 0; t < mine.size(); t += deal_rows) {
+        int best = 0;
+        for (int i = 0; i < nc; i++) {
+            credit[i] += g_ctx[i].speed / wsum;
+            if (credit[i] > credit[best] + 1e-12) best = i;
+        }
+        credit[best] -= 1.0;
+        for (size_t k = t; k < std::min(mine.size(), t + deal_rows); k++) rows[best].push_back(mine[k]);
+    }
+
+    std::vector<rt_stats> st(nc);
+    std::vector<int> rc(nc, RT_OK);
+    std::vector<std::string> msg(nc);
+    auto work = [&](int i) {
+        rt_opts o = base;
+        o.rows = rows[i].empty() ? (const uint32_t *)&o : rows[i].data();     // non-null: an empty list is a list
+        o.row_count = (uint32_t)rows[i].size();
+        memset(&st[i], 0, sizeof(rt_stats));
+        o.stats = &st[i];
+        rc[i] = render_common(g_ctx[i], cam, rgba, width, height, spp, max_depth, &o, false);
+        if (rc[i] != RT_OK) msg[i] = g_err;
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < nc; i++) th.emplace_back(work, i);
+    work(0);
+    for (auto &t : th) t.join();
+    for (int i = 0; i < nc; i++)
+        if (rc[i] != RT_OK) return fail(rc[i], "device %d: %s", g_ctx[i].device, msg[i].c_str());
+
+    rt_stats total;
+    memset(&total, 0, sizeof total);
+    for (int i = 0; i < nc; i++) {
+        total.samples += st[i].samples; total.rays += st[i].rays; total.sphere_tests += st[i].sphere_tests;
+        total.kernel_ms = std::max(total.kernel_ms, st[i].kernel_ms);
+        total.resolve_ms = std::max(total.resolve_ms, st[i].resolve_ms);
+        total.chunk_spp = std::max(total.chunk_spp, st[i].chunk_spp);
+        if (st[i].kernel_ms > 0.0 && !rows[i].empty())
+            g_ctx[i].speed = (double)rows[i].size() / st[i].kernel_ms;
+    }
+    // keep the weights comparable and no context starved by one odd timing
+    double mean = 0.0;
+    for (int i = 0; i < nc; i++) mean += g_ctx[i].speed / nc;
+    for (int i = 0; i < nc; i++) g_ctx[i].speed = std::min(1.33, std::max(0.75, g_ctx[i].speed / mean));
+    total.total_ms = std::chrono::duration<double, std::milli>(clk::now() - t_start).count();
+    if (base.stats) *base.stats = total;
     return RT_OK;
 }
 
 int rt_render(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height, int spp, int max_depth,
               const rt_opts *opts)
 {
-    return render_common(cam, rgba, width, height, spp, max_depth, opts, false);
+    if (g_nctx == 0) return fail(RT_ERR_STATE, "rt_render: rt_init has not been called");
+    if (g_nctx > 1) return render_on_all(cam, rgba, width, height, spp, max_depth, opts);
+    return render_common(g_ctx[0], cam, rgba, width, height, spp, max_depth, opts, false);
 }
 
 int rt_render_device(const rt_camera *cam, uint8_t *rgba_dev, uint32_t width, uint32_t height, int spp,
                      int max_depth, const rt_opts *opts)
 {
-    return render_common(cam, rgba_dev, width, height, spp, max_depth, opts, true);
+    if (g_nctx == 0) return fail(RT_ERR_STATE, "rt_render: rt_init has not been called");
+    if (g_nctx > 1) return fail(RT_ERR_STATE, "rt_render_device: device buffers belong to one device; the library was opened on %d", g_nctx);
+    return render_common(g_ctx[0], cam, rgba_dev, width, height, spp, max_depth, opts, true);
 }
 
 int rt_render_progressive(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height, int spp,
                           int max_depth, const rt_opts *opts, uint32_t frame_index)
 {
-    return render_common(cam, rgba, width, height, spp, max_depth, opts, false, (int64_t)frame_index);
+    if (g_nctx == 0) return fail(RT_ERR_STATE, "rt_render: rt_init has not been called");
+    if (g_nctx > 1) return fail(RT_ERR_STATE, "rt_render_progressive: the running sums live on one device; the library was opened on %d", g_nctx);
+    return render_common(g_ctx[0], cam, rgba, width, height, spp, max_depth, opts, false, (int64_t)frame_index);
 }
 
 uint32_t rt_part_rows(uint32_t height, int tile_rows, int part_index, int part_count)
@@ -531,18 +664,8 @@ int rt_scene_generate(int half_extent, uint32_t lcg_seed, rt_sphere *out, size_t
 
 void rt_shutdown(void)
 {
-    if (!g.inited) return;
-    (void)hipSetDevice(g.device);
-    (void)hipStreamSynchronize(g.stream);
-    g.geom.release(); g.matA.release(); g.matB.release(); g.pairs.release();
-    g.partial.release(); g.running.release(); g.rows.release(); g.counters.release(); g.rgba.release(); g.accum.release(); g.hit.release();
-    if (g.ev0) (void)hipEventDestroy(g.ev0);
-    if (g.ev1) (void)hipEventDestroy(g.ev1);
-    if (g.ev2) (void)hipEventDestroy(g.ev2);
-    if (g.stream) (void)hipStreamDestroy(g.stream);
-    g = State();
-    trace_forget_strict();
-    trace_forget_fast();
+    for (int i = 0; i < kMaxContexts; i++) release_ctx(g_ctx[i]);
+    g_nctx = 0;
 }
 
 }  // extern "C"

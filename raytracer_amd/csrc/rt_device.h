@@ -81,12 +81,27 @@ __host__ __device__ inline uint32_t part_row_at(uint32_t k, int tile_rows, int p
     return (t * (uint32_t)part_count + (uint32_t)part_index) * tr + r;
 }
 
-hipError_t launch_trace_strict(const TraceParams &p, bool geom_global, int blocks, size_t lds_bytes, hipStream_t s);
-hipError_t launch_trace_fast(const TraceParams &p, bool geom_global, int blocks, size_t lds_bytes, hipStream_t s);
+// The dynamic-LDS attribute and the occupancy answer depend only on (device, kernel, LDS bytes):
+// each device context looks them up once per change of scene size, not once per frame.
+struct LaunchCache {
+    size_t attr_lds[2][2][2];     // [build][mode][geom_global]: LDS size the attribute was last set to
+    size_t occ_lds[2][2];         // [build][geom_global]
+    int occ_blocks[2][2];
+    LaunchCache() { reset(); }
+    void reset()
+    {
+        for (int b = 0; b < 2; b++)
+            for (int g = 0; g < 2; g++) {
+                occ_lds[b][g] = (size_t)-1; occ_blocks[b][g] = 1;
+                for (int m = 0; m < 2; m++) attr_lds[b][m][g] = (size_t)-1;
+            }
+    }
+};
+
+hipError_t launch_trace_strict(LaunchCache &c, const TraceParams &p, bool geom_global, int blocks, size_t lds_bytes, hipStream_t s);
+hipError_t launch_trace_fast(LaunchCache &c, const TraceParams &p, bool geom_global, int blocks, size_t lds_bytes, hipStream_t s);
 hipError_t launch_resolve(const ResolveParams &p, hipStream_t s);
-int trace_blocks_per_cu_strict(bool geom_global, size_t lds_bytes);
-int trace_blocks_per_cu_fast(bool geom_global, size_t lds_bytes);
-void trace_forget_strict();   // rt_shutdown / device change: drop the cached launch set-up
-void trace_forget_fast();
+int trace_blocks_per_cu_strict(LaunchCache &c, bool geom_global, size_t lds_bytes);
+int trace_blocks_per_cu_fast(LaunchCache &c, bool geom_global, size_t lds_bytes);
 
 }  // namespace rtmi

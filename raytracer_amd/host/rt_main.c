@@ -5,7 +5,7 @@
  * a caller-owned RGBA8 buffer, then write the buffer out.
  *
  *   rt_main (--scene spheres.bin | --generate HALF) [--width 400] [--spp 10] [--depth 20] [--out frame.ppm|.tga]
- *           [--strict] [--const-u] [--seed N] [--chunk N] [--device N] [--frames N]
+ *           [--strict] [--const-u] [--seed N] [--chunk N] [--device N | --devices 0,1,...] [--frames N]
  *
  * --generate HALF builds the scene with rt_scene_generate (init_scene with its random block over
  * [-HALF, HALF)^2; 11 = the reference's final scene, 0 = its shipped three-sphere scene).
@@ -54,6 +54,7 @@ int main(int argc, char **argv)
     const char *scene = NULL, *out = NULL;
     uint32_t width = 400;
     int spp = 10, depth = 20, device = 0, frames = 1, generate = -1;      /* init_camera's defaults, Main.c:926-927 */
+    int devices[16], ndevices = 0;
     rt_opts o;
     rt_stats st;
     memset(&o, 0, sizeof o);
@@ -75,6 +76,12 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--seed")) { o.seed = (uint32_t)strtoul(v, NULL, 0); i++; }
         else if (!strcmp(a, "--chunk")) { o.chunk_spp = atoi(v); i++; }
         else if (!strcmp(a, "--device")) { device = atoi(v); i++; }
+        else if (!strcmp(a, "--devices")) {                /* 0,1,2,...: several GPUs in this process */
+            const char *q = v;
+            ndevices = 0;
+            while (*q && ndevices < 16) { devices[ndevices++] = (int)strtol(q, (char **)&q, 10); if (*q == ',') q++; }
+            i++;
+        }
         else if (!strcmp(a, "--frames")) { frames = atoi(v); i++; }
         else { fprintf(stderr, "rt_main: unknown option %s\n", a); return 2; }
     }
@@ -106,7 +113,7 @@ int main(int argc, char **argv)
     uint8_t *rgba = (uint8_t *)malloc((size_t)width * height * 4);    /* the caller owns the framebuffer */
     if (!rgba) return 1;
 
-    if (rt_init(device) || rt_set_world(spheres, n) || rt_camera_setup(&cp, width, height, &cam)) {
+    if ((ndevices > 0 ? rt_init_devices(devices, ndevices) : rt_init(device)) || rt_set_world(spheres, n) || rt_camera_setup(&cp, width, height, &cam)) {
         fprintf(stderr, "rt_main: %s\n", rt_last_error());
         return 1;
     }

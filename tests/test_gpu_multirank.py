@@ -52,3 +52,36 @@ def test_bench_two_ranks_one_gpu(tmp_path):
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["value"] > 0 and sum(out["config"]["rows_per_rank"]) == 360
     assert out["roofline"]["frac"] > 0
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_several_contexts_in_one_process(rt, strict):
+    """rt_init_devices: three contexts (sharing the one device of the test box) split a frame by
+    rows, one host thread each.  Image, accumulators, hit indices and ray counts equal the
+    single-context call; the deal adapts between frames without changing the image."""
+    import raytracer_amd as m
+    sph = load_scene("sf")
+    W, H = 240, m.height_for(240)
+    rt.set_world(sph)
+    cam = rt.camera(W, H)
+    one = rt.render(cam, W, H, 5, 20, strict_fp=strict, seed=9, chunk_spp=2, want_hit=True, want_accum=True)
+    try:
+        m.init_devices([0, 0, 0])
+        m.set_world(sph)
+        for frame in range(3):                                    # later frames use measured speeds
+            many = m.render(cam, W, H, 5, 20, strict_fp=strict, seed=9, chunk_spp=2, want_hit=True, want_accum=True)
+            assert np.array_equal(many["rgba"], one["rgba"])
+            assert np.array_equal(many["accum"], one["accum"]) and np.array_equal(many["hit"], one["hit"])
+            assert int(many["stats"].rays) == int(one["stats"].rays)
+            assert int(many["stats"].samples) == W * H * 5
+        # a caller's own partition is split further, not overridden
+        part = np.zeros((H, W, 4), np.uint8)
+        m.render(cam, W, H, 5, 20, strict_fp=strict, seed=9, chunk_spp=2, part_index=1, part_count=2, out=part)
+        rows = m.part_row_map(H, 16, 1, 2)
+        assert np.array_equal(part[rows], one["rgba"][rows])
+        other = np.setdiff1d(np.arange(H), rows)
+        assert not part[other].any()
+        with pytest.raises(m.RtError, match="one device"):
+            m.render_progressive(cam, W, H, 1, 5, 0)
+    finally:
+        m.init(0)                                                  # back to the session fixture's state
