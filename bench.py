@@ -124,6 +124,7 @@ def main():
         part.rg = RowGather(part.rows, W, 4, torch.uint8, dev, rank, world, via_host=(args.backend == "gloo"))
 
     deal([1.0] * world)                                            # equal weights = tile t -> rank t % world
+    part.rg.connect()                                              # peer connections exist before anything is timed
 
     def sync():
         if world > 1:

@@ -66,6 +66,13 @@ class RowGather:
             self._done[self._cur] = None
         return self._send[self._cur]
 
+    def connect(self):
+        """One gather of whatever the buffers hold: makes the backend set up its peer connections
+        (RCCL opens them on first use) outside any timed region."""
+        self._gather(self._send[self._cur])
+        if self._on_gpu:
+            torch.cuda.synchronize()
+
     def gather(self):
         """Collect self.mine from all ranks into self.full on rank 0; then switch send buffers."""
         full = self._gather(self._send[self._cur])
