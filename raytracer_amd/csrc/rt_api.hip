@@ -491,17 +491,18 @@ static int render_on_all(const rt_camera *cam, uint8_t *rgba, uint32_t width, ui
     std::vector<rt_stats> st(nc);
     std::vector<int> rc(nc, RT_OK);
     std::vector<std::string> msg(nc);
+    for (int i = 0; i < nc; i++) memset(&st[i], 0, sizeof(rt_stats));
     auto work = [&](int i) {
+        if (rows[i].empty()) return;                     // fewer tiles than contexts
         rt_opts o = base;
-        o.rows = rows[i].empty() ? (const uint32_t *)&o : rows[i].data();     // non-null: an empty list is a list
+        o.rows = rows[i].data();
         o.row_count = (uint32_t)rows[i].size();
-        memset(&st[i], 0, sizeof(rt_stats));
         o.stats = &st[i];
         rc[i] = render_common(g_ctx[i], cam, rgba, width, height, spp, max_depth, &o, false);
         if (rc[i] != RT_OK) msg[i] = g_err;
     };
     std::vector<std::thread> th;
-    for (int i = 1; i < nc; i++) th.emplace_back(work, i);
+    for (int i = 1; i < nc; i++) if (!rows[i].empty()) th.emplace_back(work, i);
     work(0);
     for (auto &t : th) t.join();
     for (int i = 0; i < nc; i++)

@@ -81,6 +81,10 @@ def test_several_contexts_in_one_process(rt, strict):
         assert np.array_equal(part[rows], one["rgba"][rows])
         other = np.setdiff1d(np.arange(H), rows)
         assert not part[other].any()
+        # fewer tiles than contexts: two rows in all
+        tiny = np.zeros((H, W, 4), np.uint8)
+        m.render(cam, W, H, 5, 20, strict_fp=strict, seed=9, chunk_spp=2, rows=[7, 100], out=tiny)
+        assert np.array_equal(tiny[[7, 100]], one["rgba"][[7, 100]]) and not tiny[:7].any()
         with pytest.raises(m.RtError, match="one device"):
             m.render_progressive(cam, W, H, 1, 5, 0)
     finally:
