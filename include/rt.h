@@ -207,6 +207,15 @@ uint32_t rt_height_for(uint32_t width, float aspect_ratio);
  * small.  Pure host code. */
 int rt_scene_generate(int half_extent, uint32_t lcg_seed, rt_sphere *out, size_t cap, size_t *count);
 
+/* Optional: page-locked host memory for a framebuffer the caller keeps for many frames (in place
+ * of the arena block of Main.c:998, which is also the texture upload source of render_to_screen,
+ * Main.c:935): rt_render's read-back of a whole frame into it is one DMA transfer instead of a
+ * staged copy.  Any other host memory works too.  NULL if the memory cannot be had (text in
+ * rt_last_error).  Thin wrappers over hipHostMalloc / hipHostFree, so that a C host needs no HIP
+ * headers.  No reference counterpart. */
+void *rt_host_alloc(size_t bytes);
+void rt_host_free(void *ptr);
+
 /* Frees everything rt_init / rt_set_world created. */
 void rt_shutdown(void);
 

@@ -61,7 +61,7 @@ assert SPHERE_DTYPE.itemsize == 40
 
 EXPORTS = ["rt_init", "rt_init_devices", "rt_set_world", "rt_render", "rt_render_device", "rt_render_progressive", "rt_part_rows",
            "rt_part_row_at", "rt_camera_setup", "rt_camera_defaults", "rt_height_for",
-           "rt_scene_generate", "rt_shutdown", "rt_last_error"]
+           "rt_scene_generate", "rt_host_alloc", "rt_host_free", "rt_shutdown", "rt_last_error"]
 
 _lib = None
 
@@ -106,6 +106,10 @@ def lib():
         L.rt_height_for.argtypes = [C.c_uint32, C.c_float]
         L.rt_scene_generate.restype = C.c_int
         L.rt_scene_generate.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.rt_host_alloc.restype = C.c_void_p
+        L.rt_host_alloc.argtypes = [C.c_size_t]
+        L.rt_host_free.restype = None
+        L.rt_host_free.argtypes = [C.c_void_p]
         L.rt_shutdown.restype = None
         L.rt_last_error.restype = C.c_char_p
         _lib = L
@@ -125,6 +129,23 @@ def init_devices(devices):
     """rt_init_devices: several GPUs in this one process (rt_render splits the rows among them)."""
     arr = (C.c_int * len(devices))(*devices)
     _check(lib().rt_init_devices(arr, len(devices)), "rt_init_devices")
+
+
+def host_framebuffer(height, width):
+    """rt_host_alloc: a page-locked RGBA8 framebuffer as a numpy array (DMA read-back).  Release it
+    with host_free(array) when no longer used."""
+    nbytes = height * width * 4
+    p = lib().rt_host_alloc(nbytes)
+    if not p:
+        raise RtError("rt_host_alloc failed: %s" % lib().rt_last_error().decode())
+    buf = (C.c_uint8 * nbytes).from_address(p)
+    arr = np.frombuffer(buf, dtype=np.uint8).reshape(height, width, 4)
+    arr[...] = 0
+    return arr
+
+
+def host_free(array):
+    lib().rt_host_free(array.ctypes.data)
 
 
 def shutdown():

@@ -255,9 +255,15 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
     }
 
     // read back (host-pointer entry) and/or wait
+    // A frame that owns all rows is copied straight into the caller's buffer: by the DMA engine if
+    // the buffer came from rt_host_alloc, staged by the runtime otherwise.
+    const bool whole_image = !device_ptrs && !explicit_rows && part_count == 1 && npix > 0;
+    if (whole_image) HIP_TRY(hipMemcpyAsync(rgba, d_rgba, (size_t)npix * 4, hipMemcpyDeviceToHost, g.stream));
     if (!device_ptrs && npix > 0) {
-        g.h_rgba.resize((size_t)npix * 4);
-        HIP_TRY(hipMemcpyAsync(g.h_rgba.data(), d_rgba, (size_t)npix * 4, hipMemcpyDeviceToHost, g.stream));
+        if (!whole_image) {
+            g.h_rgba.resize((size_t)npix * 4);
+            HIP_TRY(hipMemcpyAsync(g.h_rgba.data(), d_rgba, (size_t)npix * 4, hipMemcpyDeviceToHost, g.stream));
+        }
         if (o.accum_out) {
             g.h_accum.resize((size_t)npix * 3);
             HIP_TRY(hipMemcpyAsync(g.h_accum.data(), d_accum, (size_t)npix * 12, hipMemcpyDeviceToHost, g.stream));
@@ -272,7 +278,7 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
     if (!device_ptrs) {
         for (uint32_t k = 0; k < rows; k++) {
             const uint32_t y = explicit_rows ? o.rows[k] : rt_part_row_at(k, tile_rows, part_index, part_count);
-            memcpy(rgba + (size_t)y * width * 4, g.h_rgba.data() + (size_t)k * width * 4, (size_t)width * 4);
+            if (!whole_image) memcpy(rgba + (size_t)y * width * 4, g.h_rgba.data() + (size_t)k * width * 4, (size_t)width * 4);
             if (o.accum_out) memcpy(o.accum_out + (size_t)y * width * 3, g.h_accum.data() + (size_t)k * width * 3, (size_t)width * 12);
             if (o.hit_index_out) memcpy(o.hit_index_out + (size_t)y * width, g.h_hit.data() + (size_t)k * width, (size_t)width * 4);
         }
@@ -661,6 +667,23 @@ int rt_scene_generate(int half_extent, uint32_t lcg_seed, rt_sphere *out, size_t
     *count = n;
     if (overflow) return fail(RT_ERR_ARG, "rt_scene_generate: %zu objects do not fit %zu records", n, cap);
     return RT_OK;
+}
+
+void *rt_host_alloc(size_t bytes)
+{
+    if (g_nctx == 0) { fail(RT_ERR_STATE, "rt_host_alloc: rt_init has not been called"); return nullptr; }
+    void *p = nullptr;
+    if (hipSetDevice(g_ctx[0].device) != hipSuccess || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        fail(RT_ERR_NOMEM, "rt_host_alloc: %zu bytes of page-locked memory are not available", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void rt_host_free(void *ptr)
+{
+    if (ptr) (void)hipHostFree(ptr);
 }
 
 void rt_shutdown(void)

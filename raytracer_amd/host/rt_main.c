@@ -110,13 +110,18 @@ int main(int argc, char **argv)
     rt_camera_params cp;
     rt_camera cam;
     rt_camera_defaults(&cp);
-    uint8_t *rgba = (uint8_t *)malloc((size_t)width * height * 4);    /* the caller owns the framebuffer */
-    if (!rgba) return 1;
+    /* the caller owns the framebuffer; page-locked memory makes the read-back one DMA transfer */
+    uint8_t *rgba = NULL;
+    int rgba_locked = 0;
 
     if ((ndevices > 0 ? rt_init_devices(devices, ndevices) : rt_init(device)) || rt_set_world(spheres, n) || rt_camera_setup(&cp, width, height, &cam)) {
         fprintf(stderr, "rt_main: %s\n", rt_last_error());
         return 1;
     }
+    rgba = (uint8_t *)rt_host_alloc((size_t)width * height * 4);
+    rgba_locked = rgba != NULL;
+    if (!rgba) rgba = (uint8_t *)malloc((size_t)width * height * 4);
+    if (!rgba) { fprintf(stderr, "rt_main: no memory for the framebuffer\n"); return 1; }
     for (int fr = 0; fr < frames; fr++) {
         if (rt_render(&cam, rgba, width, height, spp, depth, &o)) {
             fprintf(stderr, "rt_main: %s\n", rt_last_error());
@@ -133,7 +138,7 @@ int main(int argc, char **argv)
                                                          : write_ppm(out, rgba, width, height);
     }
     rt_shutdown();
-    free(rgba);
+    if (rgba_locked) rt_host_free(rgba); else free(rgba);
     free(spheres);
     return rc ? 1 : 0;
 }

@@ -118,6 +118,28 @@ def test_device_pointer_entry_matches_host_entry(rt):
     assert np.array_equal(bits(acc.cpu().numpy()), bits(host["accum"][rows]))
 
 
+def test_page_locked_framebuffer(rt):
+    """rt_host_alloc: a whole frame read back into page-locked memory equals the frame read back into
+    ordinary memory; partial frames and the other outputs keep working with it."""
+    _, W, H = load_camera_golden(400)
+    rt.set_world(load_scene("sf"))
+    cam = rt.camera(W, H)
+    ref = rt.render(cam, W, H, 2, 20, seed=3, chunk_spp=1, want_hit=True)
+    buf = rt.host_framebuffer(H, W)
+    try:
+        got = rt.render(cam, W, H, 2, 20, seed=3, chunk_spp=1, want_hit=True, out=buf)
+        assert np.array_equal(buf, ref["rgba"]) and np.array_equal(got["hit"], ref["hit"])
+        buf[...] = 0
+        rt.render(cam, W, H, 2, 20, seed=3, chunk_spp=1, part_index=0, part_count=2, out=buf)
+        rows = rt.part_row_map(H, 16, 0, 2)
+        assert np.array_equal(buf[rows], ref["rgba"][rows]) and not buf[np.setdiff1d(np.arange(H), rows)].any()
+        for f in range(2):
+            rt.render_progressive(cam, W, H, 1, 20, f, seed=3, chunk_spp=1, out=buf)
+        assert np.array_equal(buf, ref["rgba"])
+    finally:
+        rt.host_free(buf)
+
+
 def test_fast_build_is_deterministic_and_statistically_equal_to_strict(rt):
     _, W, H = load_camera_golden(400)
     rt.set_world(load_scene("sf"))

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import raytracer_amd as rt
 w = int(sys.argv[1]) if len(sys.argv) > 1 else 1920
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-scene = sys.argv[3] if len(sys.argv) > 3 else "sg"
+scene = sys.argv[3] if len(sys.argv) > 3 and not sys.argv[3].startswith("--") else "sg"
 sph = np.fromfile(os.path.join(ROOT, "tests", "golden", "scene_%s.bin" % scene), dtype=rt.SPHERE_DTYPE)
 rt.init(0)
 rt.set_world(sph)
@@ -16,7 +16,9 @@ p = rt.default_params()
 if scene == "sg":
     p.pos = rt.Vec3(9.0, 7.0, 3.0)
 cam = rt.camera(w, h, p)
-buf = np.zeros((h, w, 4), np.uint8)
+pin = "--no-pin" not in sys.argv
+buf = rt.host_framebuffer(h, w) if pin else np.zeros((h, w, 4), np.uint8)   # the host keeps this framebuffer
+print("framebuffer %s" % ("page-locked (rt_host_alloc): DMA read-back" if pin else "pageable"))
 for spp in (1, 4):
     rt.render_progressive(cam, w, h, spp, 50, 0, out=buf)          # warm-up, allocations
     t0 = time.perf_counter()
@@ -26,4 +28,6 @@ for spp in (1, 4):
     dt = time.perf_counter() - t0
     print("%s %dx%d progressive %d spp/frame, depth 50: %.1f frames/s with read-back (%.2f ms/frame, kernel %.2f ms), %.1f Msamples/s"
           % (scene, w, h, spp, frames / dt, dt / frames * 1e3, km / frames, w * h * spp * frames / dt / 1e6), flush=True)
+if pin:
+    rt.host_free(buf)
 rt.shutdown()
