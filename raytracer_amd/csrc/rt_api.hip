@@ -415,7 +415,7 @@ int rt_set_world(const rt_sphere *spheres, size_t count)
     for (int i = 0; i < n && nbig < kMaxBig; i++)
         if (extent[i] > big_from && n > 1) { is_big[i] = 1; big[nbig++] = i; }
     double c_near = 0.0;
-    std::vector<float> pairs((size_t)n_pad * 4);
+    std::vector<float> pairs((size_t)n_pad * 4 + 8, 0.0f);     // one spare record: the scan loads one pair ahead
     for (int i = 0; i < n_pad; i++) {
         float *q = &pairs[(size_t)(i / 2) * 8 + (i & 1)];
         const float inf = std::numeric_limits<float>::infinity();

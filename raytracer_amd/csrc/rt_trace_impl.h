@@ -293,10 +293,12 @@ __device__ __forceinline__ void scan_spheres(const TraceParams &p, const float4 
     const_f8 *gp = (const_f8 *)p.pairs;
     const int npairs = p.n_pad >> 1;
     int cnt = 0;
+    f8 ahead = gp[0];                      // loaded one pair ahead: a wave alone on its SIMD does not wait per pair
     for (int k0 = 0; k0 < npairs; k0 += kPairBatch) {
 #pragma unroll
         for (int u = 0; u < kPairBatch; u++) {
-            const f8 s = gp[k0 + u];
+            const f8 s = ahead;
+            ahead = gp[k0 + u + 1];
             const f2 cx = {s[0], s[1]}, cy = {s[2], s[3]}, cz = {s[4], s[5]};
             f2 h = __builtin_elementwise_fma(cx, (f2)ux, (f2)ndo);
             h = __builtin_elementwise_fma(cy, (f2)uy, h);
