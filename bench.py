@@ -139,10 +139,11 @@ def main():
 
     for i in range(args.warmup):
         st = step()
-        if i == 0 and world > 1 and not args.no_rebalance:
+        if world > 1 and not args.no_rebalance and i < max(1, args.warmup - 1):
             # MI355X devices hold different clocks on this compute-bound kernel (10 % apart is
             # common): deal the row tiles in proportion to the speed each rank just showed, so
-            # that all ranks finish together.  The image does not depend on the deal.
+            # that all ranks finish together (again after every warm-up step but the last, which
+            # runs the final deal untimed).  The image does not depend on the deal.
             speed = torch.zeros(world, dtype=torch.float64, device=coll_dev)
             speed[rank] = len(part.rows[rank]) / max(st.kernel_ms, 1e-6)
             dist.all_reduce(speed, op=dist.ReduceOp.SUM)
