@@ -438,6 +438,24 @@ def test_strict_build_matches_checker_on_random_scenes(rt, n, seed):
         assert (r["hit"] >= 0).mean() > 0.2                  # the view does see the scene
 
 
+@pytest.mark.parametrize("W,H,spp,depth", [(1, 1, 1, 1), (3, 2, 2, 3), (65, 1, 3, 50), (1, 70, 5, 2), (257, 3, 1, 50)])
+def test_odd_image_sizes_match_checker(rt, W, H, spp, depth):
+    """Images smaller than a wave, a workgroup or a unit pool, in both summation modes."""
+    sph = load_scene("sf")
+    rt.set_world(sph)
+    p = rt.default_params()
+    cam = rt.camera(W, H, p)
+    ccam = rc.Camera.from_buffer_copy(bytes(cam))
+    for chunk in (0, 1, rt.CHUNK_AUTO):
+        r = rt.render(cam, W, H, spp, depth, strict_fp=True, seed=2, chunk_spp=chunk, want_hit=True, want_accum=True)
+        used = int(r["stats"].chunk_spp)
+        c = rc.render(ccam, sph, W, H, spp, depth, rng=rc.RNG_COUNTER, seed=2, chunk_spp=used, want_hit=True, want_accum=True)
+        assert np.array_equal(r["rgba"], c["rgba"]) and np.array_equal(r["hit"], c["hit"])
+        assert np.array_equal(r["accum"].view(np.uint32), c["accum"].view(np.uint32))
+        f = rt.render(cam, W, H, spp, depth, strict_fp=False, seed=2, chunk_spp=chunk)
+        assert (f["rgba"][..., 3] == 255).all() and int(f["stats"].samples) == W * H * spp
+
+
 @pytest.mark.parametrize("strict", [True, False])
 def test_auto_chunk(rt, strict):
     """RT_CHUNK_AUTO: the library reports the unit size it chose, and the image is the one an
