@@ -295,8 +295,9 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             st.rays = c[1];
 #ifdef RT_DIAG
             fprintf(stderr, "diag: wave scans %llu; per wave scan: pair branches taken %.1f, filter passes %.1f, "
-                    "queued candidates %.2f, drain iterations %.2f\n",
-                    c[5], (double)c[2] / c[5], (double)c[7] / c[5], (double)c[3] / c[5], (double)c[4] / c[5]);
+                    "queued candidates %.2f, drain iterations %.2f, live lanes %.1f; rays traced in shared-ray mode %llu of %llu\n",
+                    c[5], (double)c[2] / c[5], (double)c[7] / c[5], (double)c[3] / c[5], (double)c[4] / c[5],
+                    (double)(c[6] & ((1ULL << 40) - 1)) / c[5], c[6] >> 40, c[1]);
 #endif
             st.sphere_tests = c[1] * (uint64_t)g.n;
             float ms = 0.0f;

@@ -242,7 +242,7 @@ __device__ __forceinline__ void exact_test(const float4 *s_geom, int i, Probe &q
 
 #ifdef RT_DIAG
 // Diagnostic build only: where the non-scan instructions go.
-struct Diag { uint32_t branches, passes, drain_iters, drain_lanes, scans; };
+struct Diag { uint32_t branches, passes, drain_iters, drain_lanes, scans, scan_lanes, shared_rays; };
 #define RT_DIAG_ARG , Diag &dg
 #define RT_DIAG_PASS , dg
 #else
@@ -469,21 +469,29 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(cons
     bool need_unit = true;     // lane must pull a new work unit
     bool need_sample = true;   // lane must start a new sample
     uint32_t rays = 0;
-    uint32_t pool_next = 0, pool_end = 0;
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const unsigned long long static_units = (unsigned long long)gridDim.x * waves_per_block * kPoolUnits;
+    const unsigned long long first = (unsigned long long)(blockIdx.x * waves_per_block + (threadIdx.x >> 6)) * kPoolUnits;
+    uint32_t pool_next = first < total ? (uint32_t)first : total;
+    uint32_t pool_end = first + kPoolUnits < total ? (uint32_t)(first + kPoolUnits) : total;
+    pool_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_next);       // wave-uniform by construction
+    pool_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_end);
 #ifdef RT_DIAG
-    Diag dg = {0, 0, 0, 0, 0};
+    Diag dg = {0, 0, 0, 0, 0, 0, 0};
 #endif
 
     for (;;) {
         // ---- pull work units ----------------------------------------------------------
         // The wave keeps a pool of kPoolUnits consecutive units (wave-uniform registers) and
         // hands them to the lanes that finished one; the one global counter is touched once
-        // per pool, not once per hand-out (8192 waves on one address saturate the atomic unit).
+        // per pool, not once per hand-out (thousands of waves on one address saturate the atomic
+        // unit).  The first pool of every wave is static (units wave*64 ...), so a launch does
+        // not open with one atomic per wave either; the counter hands out what lies beyond.
         unsigned long long want = __ballot(active && need_unit);
         while (want != 0ULL) {
             if (pool_next == pool_end) {
                 unsigned long long b64 = 0;
-                if (lane == 0) b64 = atomicAdd(&p.counters[0], (unsigned long long)kPoolUnits);
+                if (lane == 0) b64 = atomicAdd(&p.counters[0], (unsigned long long)kPoolUnits) + static_units;
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64);
                 const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b64 >> 32));
                 if (hi != 0U || lo >= total) {              // no units left: the waiting lanes retire
@@ -559,6 +567,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(cons
         const unsigned long long live = __ballot(active);
         if (__popcll(live) <= p.coop_max) shared_ray_hit(p, s_geom, lane, live, q);
         else scan_spheres(p, s_geom, queue, lane, q.dx, q.dy, q.dz, 1.9073486e-6f, q RT_DIAG_PASS);   // 2^-19
+#ifdef RT_DIAG
+        if (__popcll(live) <= p.coop_max) dg.shared_rays += (uint32_t)__popcll(live); else dg.scan_lanes += (uint32_t)__popcll(live);
+#endif
         if (L.zero_dir) q.hit = -1;
 #endif
         const float closest = q.closest;
@@ -683,6 +694,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(cons
         atomicAdd(&p.counters[4], (unsigned long long)dg.drain_iters);
         atomicAdd(&p.counters[5], (unsigned long long)dg.scans);
         atomicAdd(&p.counters[7], (unsigned long long)dg.passes);
+        atomicAdd(&p.counters[6], ((unsigned long long)dg.shared_rays << 40) | (unsigned long long)dg.scan_lanes);
     }
 #endif
 }
