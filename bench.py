@@ -193,9 +193,9 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
                          # HBM bytes per launch of trace_kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
                          # passes on this command (the counter files are kept under profiles/;
-                         # FETCH_SIZE doubled, the gfx950 correction): 2.22 GB written + 0.20 GB read.
+                         # FETCH_SIZE doubled, the gfx950 correction): 2.27 GB written + 0.01-0.2 GB read.
                          # Only known for the default workload on one GPU, null otherwise
-                         "traffic": (2.42e9 if (world == 1 and W == 3840 and args.spp == 1000
+                         "traffic": (2.3e9 if (world == 1 and W == 3840 and args.spp == 1000
                                                 and int(stats[-1].chunk_spp) == 63 and not args.strict) else None),
                          "kernel": "trace_kernel", "kernel_ms": round(kernel_ms, 3),
                          "flop_per_sphere_test": FLOP_PER_TEST,
