@@ -8,8 +8,9 @@
 // Mapping: one lane = one stream of pixel samples.  A lane owns a work unit (pixel, chunk of
 // samples), traces its samples one after another, and immediately starts the next sample when a
 // path ends, so that every lane of the wave has a live ray whenever the wave enters the sphere
-// loop.  Lanes that run out of samples pull the next unit from a global counter; the wave
-// does that with one ballot, one atomic and a prefix count.
+// loop.  Lanes that run out of samples take the next unit from their wave's pool of 64 units
+// (one ballot and a prefix count); a wave refills its pool from a global counter with one atomic.
+// A wave with only a few rays left tests each of them with all 64 lanes (shared_ray_hit).
 //
 // Reference functions restated here (file:line under the reference tree):
 //   get_ray Main.c:776-803, sample_square :764, defocus_disk_sample :770,
