@@ -12,7 +12,7 @@ namespace rtmi {
 //   matB[i] = { refraction_index, bits(mat_type), 1.0f/r, r }
 // geom is padded to a multiple of kGeomPad with never-hit entries (r*r = -inf).
 constexpr int kGeomPad = 8;
-// Fast build: the scan over the sphere list is a conservative filter, two spheres per packed-FP32
+// Both builds: the scan over the sphere list is a conservative filter, two spheres per packed-FP32
 // instruction.  pairs[k] holds spheres 2k and 2k+1 as { cx0, cx1, cy0, cy1, cz0, cz1, k0, k1 } with
 // k = |C|^2 - r^2 (read through the scalar cache: the index is wave-uniform).  With a unit
 // direction d, the discriminant h^2 - c >= 0 is (d.C - d.O)^2 + 2 O.C - |O|^2 >= |C|^2 - r^2:
@@ -25,7 +25,7 @@ constexpr int kGeomPad = 8;
 constexpr int kMaxBig = 16;
 // Workgroups of 4 waves, one per SIMD.  The fast build fits 72 VGPRs, i.e. 7 waves per SIMD (8
 // would need 64 VGPRs and spill): 7 workgroups per CU, whose LDS (geometry image + queues) fits
-// 160 KB with 12 queue slots per lane.  The strict build needs more registers (6 waves per SIMD).
+// 160 KB with 14 queue slots per lane.  The strict build needs more registers (6 waves per SIMD).
 constexpr int kBlockThreads = 256;
 constexpr int kQueueSlotsFast = 14;        // candidate-queue slots per lane
 constexpr int kQueueSlotsStrict = 16;
