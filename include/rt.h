@@ -143,7 +143,9 @@ int rt_init(int device);
  * frame, renders them concurrently (one host thread per device) and writes every row at its
  * place in the caller's buffers; rt_stats then holds sums (samples, rays, sphere_tests) and
  * maxima (kernel_ms, resolve_ms).  The image is the single-device image, byte for byte.
- * rt_render_device and rt_render_progressive need a single device (RT_ERR_STATE otherwise).
+ * rt_render_progressive works the same way and keeps the deal of frame 0 for the sequence (each
+ * device carries the running sums of its rows); rt_render_device needs a single device
+ * (RT_ERR_STATE otherwise).
  * An id may be listed more than once (contexts sharing a device; used by the tests). */
 int rt_init_devices(const int *devices, int count);
 

@@ -455,8 +455,11 @@ int rt_set_world(const rt_sphere *spheres, size_t count)
 // are dealt in tiles to the contexts in proportion to the speed each showed in the previous frame
 // (smooth weighted round robin: every context's tiles stay spread over the image), one host thread
 // per context renders its rows into the caller's buffers.  The image does not depend on the deal.
+// Progressive frames keep the deal of frame 0 (each context carries the running sums of its rows).
+static std::vector<std::vector<uint32_t>> g_prog_rows;
+
 static int render_on_all(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height, int spp,
-                         int max_depth, const rt_opts *opts)
+                         int max_depth, const rt_opts *opts, int64_t frame_index = -1)
 {
     using clk = std::chrono::steady_clock;
     const auto t_start = clk::now();
@@ -485,7 +488,9 @@ static int render_on_all(const rt_camera *cam, uint8_t *rgba, uint32_t width, ui
     std::vector<double> credit(nc, 0.0);
     std::vector<std::vector<uint32_t>> rows(nc);
     const int deal_rows = 2;                                  // fine tiles: the split follows the weights closely
-    for (size_t t = 0; t < mine.size(); t += deal_rows) {
+    const bool reuse_deal = frame_index > 0 && (int)g_prog_rows.size() == nc;
+    if (reuse_deal) rows = g_prog_rows;
+    for (size_t t = 0; !reuse_deal && t < mine.size(); t += deal_rows) {
         int best = 0;
         for (int i = 0; i < nc; i++) {
             credit[i] += g_ctx[i].speed / wsum;
@@ -494,6 +499,8 @@ static int render_on_all(const rt_camera *cam, uint8_t *rgba, uint32_t width, ui
         credit[best] -= 1.0;
         for (size_t k = t; k < std::min(mine.size(), t + deal_rows); k++) rows[best].push_back(mine[k]);
     }
+
+    if (frame_index == 0) g_prog_rows = rows;
 
     std::vector<rt_stats> st(nc);
     std::vector<int> rc(nc, RT_OK);
@@ -505,7 +512,7 @@ static int render_on_all(const rt_camera *cam, uint8_t *rgba, uint32_t width, ui
         o.rows = rows[i].data();
         o.row_count = (uint32_t)rows[i].size();
         o.stats = &st[i];
-        rc[i] = render_common(g_ctx[i], cam, rgba, width, height, spp, max_depth, &o, false);
+        rc[i] = render_common(g_ctx[i], cam, rgba, width, height, spp, max_depth, &o, false, frame_index);
         if (rc[i] != RT_OK) msg[i] = g_err;
     };
     std::vector<std::thread> th;
@@ -554,7 +561,7 @@ int rt_render_progressive(const rt_camera *cam, uint8_t *rgba, uint32_t width, u
                           int max_depth, const rt_opts *opts, uint32_t frame_index)
 {
     if (g_nctx == 0) return fail(RT_ERR_STATE, "rt_render: rt_init has not been called");
-    if (g_nctx > 1) return fail(RT_ERR_STATE, "rt_render_progressive: the running sums live on one device; the library was opened on %d", g_nctx);
+    if (g_nctx > 1) return render_on_all(cam, rgba, width, height, spp, max_depth, opts, (int64_t)frame_index);
     return render_common(g_ctx[0], cam, rgba, width, height, spp, max_depth, opts, false, (int64_t)frame_index);
 }
 
@@ -689,6 +696,7 @@ void rt_host_free(void *ptr)
 
 void rt_shutdown(void)
 {
+    g_prog_rows.clear();
     for (int i = 0; i < kMaxContexts; i++) release_ctx(g_ctx[i]);
     g_nctx = 0;
 }

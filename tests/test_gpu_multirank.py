@@ -85,7 +85,12 @@ def test_several_contexts_in_one_process(rt, strict):
         tiny = np.zeros((H, W, 4), np.uint8)
         m.render(cam, W, H, 5, 20, strict_fp=strict, seed=9, chunk_spp=2, rows=[7, 100], out=tiny)
         assert np.array_equal(tiny[[7, 100]], one["rgba"][[7, 100]]) and not tiny[:7].any()
+        # progressive frames over several contexts: the running sums stay with the rows' owners
+        for f in range(3):
+            prog = m.render_progressive(cam, W, H, 2, 20, f, strict_fp=strict, seed=9, chunk_spp=2, want_accum=True)
+        six = rt.render(cam, W, H, 6, 20, strict_fp=strict, seed=9, chunk_spp=2, want_accum=True)
+        assert np.array_equal(prog["rgba"], six["rgba"]) and np.array_equal(prog["accum"], six["accum"])
         with pytest.raises(m.RtError, match="one device"):
-            m.render_progressive(cam, W, H, 1, 5, 0)
+            m.render_device(cam, 0, W, H, 1, 5)
     finally:
         m.init(0)                                                  # back to the session fixture's state
