@@ -105,8 +105,10 @@ typedef struct rt_opts {
     int32_t  chunk_spp;      /* samples per work unit; a pixel's sum is the in-order
                                 sum of its chunks' in-order partial sums.  0 = spp
                                 (one unit per pixel: the reference's summation order,
-                                Main.c:973-976); RT_CHUNK_AUTO = chosen for throughput
-                                (a function of image size and spp only)              */
+                                Main.c:973-976); RT_CHUNK_AUTO = chosen for throughput:
+                                a function of the FULL image's width, height and spp
+                                only (rt_chunk_for), never of the rows a call, a device
+                                or a rank owns, so the parts of a split frame agree  */
     int32_t  tile_rows;      /* multi-GPU row-tile height (0 = 16)                   */
     int32_t  part_index;     /* this call renders row tiles t with                   */
     int32_t  part_count;     /*   t % part_count == part_index  (0 or 1 = all rows)  */
@@ -140,12 +142,14 @@ int rt_init(int device);
  * (one GLFW thread, Main.c:1440-1443), so this is how its frame loop reaches several GPUs
  * without a launcher.  rt_set_world uploads to every device; rt_render deals the rows it owns to
  * the devices in 2-row tiles, in proportion to the speed each device showed in the previous
- * frame, renders them concurrently (one host thread per device) and writes every row at its
+ * frame, renders them concurrently (one persistent host thread per device) and writes every row at its
  * place in the caller's buffers; rt_stats then holds sums (samples, rays, sphere_tests) and
  * maxima (kernel_ms, resolve_ms).  The image is the single-device image, byte for byte.
  * rt_render_progressive works the same way and keeps the deal of frame 0 for the sequence (each
- * device carries the running sums of its rows); rt_render_device needs a single device
- * (RT_ERR_STATE otherwise).
+ * device carries the running sums of its rows; a frame that owns other rows than frame 0, or that
+ * follows a failed frame, is refused with RT_ERR_STATE); rt_render_device needs a single device
+ * (RT_ERR_STATE otherwise).  The calling thread's current HIP device is the same after every call
+ * of this library as before it.
  * An id may be listed more than once (contexts sharing a device; used by the tests). */
 int rt_init_devices(const int *devices, int count);
 
@@ -187,6 +191,12 @@ uint32_t rt_part_rows(uint32_t height, int tile_rows, int part_index, int part_c
 
 /* Image row of the k-th owned row of a part (inverse of the compaction above). */
 uint32_t rt_part_row_at(uint32_t k, int tile_rows, int part_index, int part_count);
+
+/* The samples per work unit a render call of a width x height image at `spp` uses for
+ * opts->chunk_spp = chunk_spp (RT_CHUNK_AUTO, 0 or an explicit size); `progressive` != 0 for
+ * rt_render_progressive, whose units must divide spp.  Pure host arithmetic; 0 on bad arguments.
+ * No reference counterpart (the reference sums a pixel's samples in one run, Main.c:973-976). */
+int rt_chunk_for(uint32_t width, uint32_t height, int spp, int chunk_spp, int progressive);
 
 /* update_camera_view (Main.c:839-904) restated on the host, quirks included
  * (tan_f32 takes turns but is fed radians, include/util.h:134,142).  A host that

@@ -21,13 +21,19 @@ REF = os.path.join(HERE, "_ref")
 GOLD = os.path.join(HERE, "..", "tests", "golden")
 
 
-def run(scene, cmd, width, spp, depth, threads=8):
+SG_CAM_POS = (9.0, 7.0, 3.0)     # eye point of the glass-heavy progressive configuration (looks at the origin)
+
+
+def run(scene, cmd, width, spp, depth, threads=8, cam_pos=None):
     exe = os.path.join(REF, "ref_harness_" + scene)
     with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
         out = f.name
+    env = dict(os.environ)
+    if cam_pos is not None:
+        env["REF_CAM_POS"] = "%r,%r,%r" % tuple(cam_pos)
     try:
         subprocess.check_call([exe, cmd, str(width), str(spp), str(depth), out, str(threads)],
-                              stderr=subprocess.DEVNULL)
+                              stderr=subprocess.DEVNULL, env=env)
         return np.fromfile(out, dtype=np.uint8)
     finally:
         os.unlink(out)
@@ -36,6 +42,7 @@ def run(scene, cmd, width, spp, depth, threads=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--long", action="store_true")
+    ap.add_argument("--cameras-only", action="store_true", help="rewrite cameras.npz (and the scene files) only")
     ap.add_argument("--sf-2048", default=None, help="use an already rendered sf 400x225 2048-spp RGBA file")
     args = ap.parse_args()
     if not os.path.exists(os.path.join(REF, "ref_harness_s3")):
@@ -62,7 +69,14 @@ def main():
         raw = run("s3", "camera", w, 1, 1)
         cams["cam_%d" % w] = raw[:76].view("<f4").copy()
         cams["wh_%d" % w] = raw[76:84].view("<u4").copy()
+    # the glass-heavy configuration's camera: the reference's update_camera_view after moving the eye
+    cams["sg_pos"] = np.asarray(SG_CAM_POS, dtype="<f4")
+    for w in (100, 1920):
+        raw = run("s3", "camera", w, 1, 1, cam_pos=SG_CAM_POS)
+        cams["cam_sg_%d" % w] = raw[:76].view("<f4").copy()
     np.savez_compressed(os.path.join(GOLD, "cameras.npz"), **cams)
+    if args.cameras_only:
+        return 0
 
     # deterministic constant-u renders + primary hit indices
     for s in ("s3", "sf"):

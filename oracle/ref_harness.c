@@ -12,6 +12,7 @@
  * usage: ref_harness_<s3|sf> <cmd> <width> <spp> <depth> <out-file> [threads]
  *   scene   raw sphere_t records (40 B each, Main.c:74-79)
  *   camera  19 f32 (pos, pixel00, du, dv, disk_u, disk_v, defocus_angle) + 2 u32 (W,H)
+ *           (environment REF_CAM_POS="x,y,z" moves the eye point for every command)
  *   mc      RGBA8 image, reference render_tile per 64x64 tile (per-tile LCG seed)
  *   mcser   RGBA8 image, render_all's loop order on one thread (seed 0)
  *   d0      int32 primary-hit index per pixel (centre ray from camera.pos)
@@ -80,6 +81,15 @@ int main(int argc, char **argv)
 
     fast_srand(0);
     init_camera(width, 16.0f / 9.0f);
+    /* REF_CAM_POS="x,y,z": another eye point, derived by the reference's own update_camera_view
+       (Main.c:839-904), as its key handler does after moving the camera (Main.c:382-458) */
+    const char *cam_pos = getenv("REF_CAM_POS");
+    if (cam_pos) {
+        float px, py, pz;
+        if (sscanf(cam_pos, "%f,%f,%f", &px, &py, &pz) != 3) { fprintf(stderr, "bad REF_CAM_POS\n"); return 2; }
+        gc.camera.pos = (vec3f_t){ .x = px, .y = py, .z = pz };
+        update_camera_view();
+    }
     init_scene();
     gc.samples_per_pixel = spp;
     gc.max_depth = depth;

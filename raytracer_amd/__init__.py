@@ -59,8 +59,8 @@ SPHERE_DTYPE = np.dtype([("center", "<f4", 3), ("radius", "<f4"), ("mat_type", "
                          ("albedo", "<f4", 3), ("fuzz", "<f4"), ("ior", "<f4")])
 assert SPHERE_DTYPE.itemsize == 40
 
-EXPORTS = ["rt_init", "rt_init_devices", "rt_set_world", "rt_render", "rt_render_device", "rt_render_progressive", "rt_part_rows",
-           "rt_part_row_at", "rt_camera_setup", "rt_camera_defaults", "rt_height_for",
+EXPORTS = ["rt_init", "rt_init_devices", "rt_set_world", "rt_render", "rt_render_device",
+           "rt_render_progressive", "rt_part_rows", "rt_part_row_at", "rt_chunk_for", "rt_camera_setup", "rt_camera_defaults", "rt_height_for",
            "rt_scene_generate", "rt_host_alloc", "rt_host_free", "rt_shutdown", "rt_last_error"]
 
 _lib = None
@@ -98,6 +98,8 @@ def lib():
         L.rt_part_rows.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int]
         L.rt_part_row_at.restype = C.c_uint32
         L.rt_part_row_at.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int]
+        L.rt_chunk_for.restype = C.c_int
+        L.rt_chunk_for.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int]
         L.rt_camera_setup.restype = C.c_int
         L.rt_camera_setup.argtypes = [C.POINTER(CameraParams), C.c_uint32, C.c_uint32, C.POINTER(Camera)]
         L.rt_camera_defaults.restype = None
@@ -242,6 +244,11 @@ def render_progressive(cam, width, height, spp, max_depth, frame_index, mode=MOD
     _check(lib().rt_render_progressive(C.byref(cam), rgba.ctypes.data, width, height, spp, max_depth,
                                        C.byref(o), frame_index), "rt_render_progressive")
     return dict(rgba=rgba, accum=acc, stats=st)
+
+
+def chunk_for(width, height, spp, chunk_spp=CHUNK_AUTO, progressive=False):
+    """rt_chunk_for: the samples per work unit a render of this full image size uses."""
+    return int(lib().rt_chunk_for(width, height, spp, chunk_spp, int(bool(progressive))))
 
 
 def render_device(cam, rgba_dev_ptr, width, height, spp, max_depth, mode=MODE_MC, strict_fp=False,

@@ -2,18 +2,24 @@
 // Owns one context per device given to rt_init / rt_init_devices (stream, events, the
 // structure-of-arrays world, scratch: per-chunk partial sums, work/ray counters, staging for
 // host-pointer callers).  With several contexts rt_render deals the image rows to them and runs
-// one host thread per context.
+// one persistent host thread per context.
 #include "../../include/rt.h"
 #include "rt_device.h"
 
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <functional>
 #include <limits>
+#include <memory>
+#include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -23,6 +29,10 @@
 using namespace rtmi;
 
 namespace {
+
+constexpr int kCounters = 16;                    // 64-bit words: [0] next work unit, [1] rays cast, the rest diagnostics
+constexpr size_t kScratchCountersBytes = 256;
+constexpr uint32_t kProgBroken = 0xffffffffu;    // prog_frames of a sequence that must restart at frame 0
 
 struct DevBuf {
     void *p = nullptr;
@@ -34,6 +44,7 @@ struct DevBuf {
         const size_t want = bytes + bytes / 4;          // headroom: a slightly larger partition must not reallocate
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) { cap = want; return e; }
+        (void)hipGetLastError();
         e = hipMalloc(&p, bytes);
         if (e == hipSuccess) cap = bytes;
         return e;
@@ -61,11 +72,13 @@ struct Ctx {
     DevBuf partial, counters, rgba, accum, hit, rows;
     // progressive accumulation (rt_render_progressive): running per-pixel sums and what they belong to
     DevBuf running;
-    uint32_t prog_w = 0, prog_h = 0, prog_npix = 0, prog_frames = 0;
-    int prog_spp = 0;
+    uint32_t prog_w = 0, prog_h = 0, prog_npix = 0, prog_frames = kProgBroken;
+    int prog_spp = 0, prog_chunk = 0;
+    std::vector<uint32_t> prog_rows;        // image row of every owned row of the sequence, in buffer order
     std::vector<uint8_t> h_rgba;
     std::vector<float> h_accum;
     std::vector<int32_t> h_hit;
+    unsigned long long last_counters[kCounters] = {0};
 };
 
 Ctx g_ctx[kMaxContexts];
@@ -85,10 +98,81 @@ int fail(int code, const char *fmt, ...)
 #define HIP_TRY(expr)                                                                     \
     do {                                                                                  \
         hipError_t e_ = (expr);                                                           \
-        if (e_ != hipSuccess)                                                             \
+        if (e_ != hipSuccess) {                                                           \
+            (void)hipGetLastError();                                                      \
             return fail(e_ == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE,         \
                         "%s failed: %s", #expr, hipGetErrorString(e_));                   \
+        }                                                                                 \
     } while (0)
+
+// The entry points select devices on the caller's thread; a host that also drives HIP or PyTorch
+// itself must find its own current device unchanged afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; } }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// Nothing may throw across the C boundary: the library's own containers and threads can
+// (std::bad_alloc, std::system_error).
+template <class F>
+int guarded(const char *what, F &&body)
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(RT_ERR_NOMEM, "%s: out of host memory", what);
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_DEVICE, "%s: %s", what, e.what());
+    } catch (...) {
+        return fail(RT_ERR_DEVICE, "%s: unknown failure", what);
+    }
+}
+
+// One persistent host thread per context beyond the first (the caller's thread drives context 0):
+// a frame hands each a job and waits; no thread is created per frame.
+class Worker {
+public:
+    Worker() : th_([this] { loop(); }) {}
+    ~Worker()
+    {
+        { std::lock_guard<std::mutex> l(mu_); quit_ = true; }
+        cv_.notify_all();
+        th_.join();
+    }
+    void start(std::function<void()> job)
+    {
+        { std::lock_guard<std::mutex> l(mu_); job_ = std::move(job); busy_ = true; }
+        cv_.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> l(mu_);
+        cv_.wait(l, [this] { return !busy_; });
+    }
+private:
+    void loop()
+    {
+        std::unique_lock<std::mutex> l(mu_);
+        for (;;) {
+            cv_.wait(l, [this] { return quit_ || busy_; });
+            if (quit_) return;
+            std::function<void()> job = std::move(job_);
+            l.unlock();
+            job();                         // jobs catch their own exceptions
+            l.lock();
+            busy_ = false;
+            cv_.notify_all();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    bool busy_ = false, quit_ = false;
+    std::thread th_;                       // last: the thread starts when every other member exists
+};
+
+std::vector<std::unique_ptr<Worker>> g_workers;     // g_workers[i - 1] serves context i
 
 inline void put3(float *d, rt_vec3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
 
@@ -110,14 +194,43 @@ inline rt_vec3 R(V3 a) { rt_vec3 r; r.x = a.x; r.y = a.y; r.z = a.z; return r; }
 inline float turns_to_rad(float v) { return v * (2 * 3.1415926535897f); }
 inline float deg_to_rad(float v) { return turns_to_rad(v / 360.f); }
 
+// Samples per work unit.  RT_CHUNK_AUTO is a function of the FULL image size and spp only, never of
+// the rows a device or a rank owns or of the device: a pixel's sum is the in-order sum of its
+// chunks' partial sums, so every part of a split frame must use the same unit size for the
+// assembled image to equal the single-device image.
+// Short units keep the end of a launch, when units run out and lanes fall idle, short; each halving
+// of the unit below 8 samples costs about 0.7 % in unit hand-outs, so only images that give a lane of
+// a full MI355X (256 CUs x 2048 lanes) fewer than 128 eight-sample units get shorter ones.  The
+// per-chunk sums of the full image are capped at 16 GiB.
+int resolve_chunk(int chunk_opt, uint32_t width, uint32_t height, int spp, bool progressive)
+{
+    if (chunk_opt != RT_CHUNK_AUTO) return (chunk_opt > 0 && chunk_opt < spp) ? chunk_opt : spp;
+    const uint64_t full = (uint64_t)width * (uint64_t)height;
+    const uint64_t max_chunks = std::max<uint64_t>(1, (16ULL << 30) / (std::max<uint64_t>(full, 1) * sizeof(float4)));
+    const uint64_t least = ((uint64_t)spp + max_chunks - 1) / max_chunks;
+    const uint64_t lanes = 256ULL * 2048ULL;
+    const uint64_t small = std::max<uint64_t>(1, full * (uint64_t)spp / (128 * lanes));
+    int chunk = (int)std::min<uint64_t>((uint64_t)spp, std::max<uint64_t>(std::min<uint64_t>(8, small), least));
+    if (progressive) while (spp % chunk != 0) chunk++;          // frames add whole chunks
+    return chunk;
+}
+
+struct Call {
+    bool device_ptrs = false;     // outputs are device pointers (compact over the owned rows)
+    int64_t frame_index = -1;     // >= 0: progressive frame
+    int chunk = 0;                // resolved samples per work unit (resolve_chunk)
+};
+
 int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height, int spp,
-                  int max_depth, const rt_opts *opts, bool device_ptrs, int64_t frame_index = -1)
+                  int max_depth, const rt_opts *opts, const Call &call)
 {
     using clk = std::chrono::steady_clock;
     const auto t_start = clk::now();
     rt_opts dflt;
     memset(&dflt, 0, sizeof dflt);
     const rt_opts &o = opts ? *opts : dflt;
+    const bool device_ptrs = call.device_ptrs;
+    const int64_t frame_index = call.frame_index;
 
     if (!g.inited) return fail(RT_ERR_STATE, "rt_render: rt_init has not been called");
     if (g.n_pad == 0) return fail(RT_ERR_STATE, "rt_render: rt_set_world has not been called");
@@ -127,9 +240,9 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
     if (spp < 1) return fail(RT_ERR_ARG, "rt_render: spp must be >= 1 (got %d)", spp);
     if (max_depth < 0) return fail(RT_ERR_ARG, "rt_render: max_depth must be >= 0 (got %d)", max_depth);
     if (o.mode != RT_MODE_MC && o.mode != RT_MODE_CONST_U) return fail(RT_ERR_ARG, "rt_render: unknown mode %d", o.mode);
-    const int chunk_opt = opts ? o.chunk_spp : RT_CHUNK_AUTO;
-    if ((chunk_opt < 0 && chunk_opt != RT_CHUNK_AUTO) || o.tile_rows < 0)
-        return fail(RT_ERR_ARG, "rt_render: negative chunk_spp or tile_rows");
+    if (o.tile_rows < 0) return fail(RT_ERR_ARG, "rt_render: negative tile_rows");
+    const int chunk = call.chunk;
+    if (chunk < 1 || chunk > spp) return fail(RT_ERR_ARG, "rt_render: bad chunk_spp %d for %d spp", chunk, spp);
     const int part_count = o.part_count > 1 ? o.part_count : 1;
     const int part_index = part_count > 1 ? o.part_index : 0;
     if (part_index < 0 || part_index >= part_count) return fail(RT_ERR_ARG, "rt_render: part_index %d outside [0,%d)", o.part_index, part_count);
@@ -147,39 +260,37 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
     const uint32_t rows = explicit_rows ? o.row_count : rt_part_rows(height, tile_rows, part_index, part_count);
     const uint32_t npix = rows * width;
     const bool progressive = frame_index >= 0;
-    int chunk = (chunk_opt > 0 && chunk_opt < spp) ? chunk_opt : spp;
-    if (chunk_opt == RT_CHUNK_AUTO) {
-        // Short units keep the end of the launch, when units run out and lanes fall idle, short;
-        // each halving of the unit below 8 samples costs about 0.7 % in unit hand-outs and takes about
-        // 1 ms off the end (measured on an eighth of the 4K frame), so launches in which a lane sees
-        // fewer than 128 eight-sample units get shorter ones.  The per-chunk sums are capped at 2 GiB.
-        const uint64_t max_chunks = std::max<uint64_t>(1, (2ULL << 30) / (std::max<uint64_t>(npix, 1) * sizeof(float4)));
-        const uint64_t least = ((uint64_t)spp + max_chunks - 1) / max_chunks;
-        const uint64_t lanes = (uint64_t)g.num_cu * 2048;
-        const uint64_t small = std::max<uint64_t>(1, (uint64_t)npix * (uint64_t)spp / (128 * lanes));
-        chunk = (int)std::min<uint64_t>((uint64_t)spp, std::max<uint64_t>(std::min<uint64_t>(8, small), least));
-        if (progressive) while (spp % chunk != 0) chunk++;          // frames add whole chunks
-    }
     const int nchunks = (spp + chunk - 1) / chunk;
     const uint64_t units = (uint64_t)npix * (uint64_t)nchunks;
     if (units >= 0xffffffffULL) return fail(RT_ERR_ARG, "rt_render: %llu work units; raise chunk_spp", (unsigned long long)units);
 
     uint32_t sample_base = o.sample_base;
+    uint32_t frames_after = 0;
     if (progressive) {
         if (max_depth < 1) return fail(RT_ERR_ARG, "rt_render_progressive: max_depth must be >= 1");
         if (spp % chunk != 0) return fail(RT_ERR_ARG, "rt_render_progressive: chunk_spp (%d) must divide spp (%d)", chunk, spp);
         if ((uint64_t)spp * (uint64_t)(frame_index + 1) > 0x7fffffffULL) return fail(RT_ERR_ARG, "rt_render_progressive: too many samples");
+        std::vector<uint32_t> owned(rows);
+        for (uint32_t k = 0; k < rows; k++) owned[k] = explicit_rows ? o.rows[k] : rt_part_row_at(k, tile_rows, part_index, part_count);
         if (frame_index == 0) {
+            g.prog_frames = kProgBroken;
             HIP_TRY(g.running.reserve((size_t)npix * sizeof(float4) + 16));
             HIP_TRY(hipMemsetAsync(g.running.p, 0, (size_t)npix * sizeof(float4), g.stream));
-            g.prog_w = width; g.prog_h = height; g.prog_npix = npix; g.prog_spp = spp; g.prog_frames = 0;
+            g.prog_w = width; g.prog_h = height; g.prog_npix = npix; g.prog_spp = spp; g.prog_chunk = chunk;
+            g.prog_rows = owned;
+            g.prog_frames = 0;
         }
-        if (g.prog_w != width || g.prog_h != height || g.prog_npix != npix || g.prog_spp != spp ||
-            (int64_t)g.prog_frames != frame_index)
+        if (g.prog_frames == kProgBroken)
+            return fail(RT_ERR_STATE, "rt_render_progressive: frame %lld does not continue a sequence (none started, or an earlier frame failed); "
+                        "start again with frame_index 0", (long long)frame_index);
+        if (g.prog_w != width || g.prog_h != height || g.prog_npix != npix || g.prog_spp != spp || g.prog_chunk != chunk ||
+            (int64_t)g.prog_frames != frame_index || g.prog_rows != owned)
             return fail(RT_ERR_STATE, "rt_render_progressive: frame %lld does not continue the sequence "
-                        "(%u frames of %ux%u at %d spp accumulated); start again with frame_index 0",
-                        (long long)frame_index, g.prog_frames, g.prog_w, g.prog_h, g.prog_spp);
+                        "(%u frames of %ux%u at %d spp in units of %d accumulated, %u rows owned); start again with frame_index 0",
+                        (long long)frame_index, g.prog_frames, g.prog_w, g.prog_h, g.prog_spp, g.prog_chunk, (unsigned)g.prog_rows.size());
         sample_base += (uint32_t)frame_index * (uint32_t)spp;
+        frames_after = g.prog_frames + 1;
+        g.prog_frames = kProgBroken;        // until this frame is complete: a failure below ends the sequence
     }
 
     rt_stats st;
@@ -194,6 +305,7 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
         if (o.accum_out) { HIP_TRY(g.accum.reserve((size_t)npix * 12 + 4)); d_accum = (float *)g.accum.p; }
         if (o.hit_index_out) { HIP_TRY(g.hit.reserve((size_t)npix * 4 + 4)); d_hit = (int32_t *)g.hit.p; }
     }
+    unsigned long long *d_counters = (unsigned long long *)g.counters.p;
 
     if (npix > 0) {
         if (max_depth == 0) {
@@ -203,7 +315,9 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             if (d_hit) HIP_TRY(hipMemsetAsync(d_hit, 0xff, (size_t)npix * 4, g.stream));
         } else {
             HIP_TRY(g.partial.reserve((size_t)units * sizeof(float4)));
-            HIP_TRY(hipMemsetAsync(g.counters.p, 0, 8 * sizeof(unsigned long long), g.stream));
+            float4 *d_partial = (float4 *)g.partial.p;
+            // the counters start at zero; the per-chunk sums need no clearing (every unit writes its sum)
+            HIP_TRY(hipMemsetAsync(d_counters, 0, kScratchCountersBytes, g.stream));
 
             TraceParams tp;
             memset(&tp, 0, sizeof tp);
@@ -229,9 +343,9 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             }
             tp.spp = spp; tp.chunk_spp = chunk; tp.nchunks = nchunks; tp.max_depth = max_depth;
             tp.mode = o.mode; tp.seed = o.seed; tp.sample_base = sample_base;
-            tp.partial = (float4 *)g.partial.p;
+            tp.partial = d_partial;
             tp.hit_index = d_hit;
-            tp.counters = (unsigned long long *)g.counters.p;
+            tp.counters = d_counters;
             tp.total_units = units;
 
             const bool geom_global = g.n > kMaxSpheresLds;
@@ -246,7 +360,7 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
                                 : launch_trace_fast(g.launch, tp, geom_global, (int)blocks, lds, g.stream));
             HIP_TRY(hipEventRecord(g.ev1, g.stream));
             ResolveParams rp;
-            rp.partial = (const float4 *)g.partial.p; rp.nchunks = nchunks; rp.npix = npix;
+            rp.partial = d_partial; rp.nchunks = nchunks; rp.npix = npix;
             rp.running = progressive ? (float4 *)g.running.p : nullptr;
             rp.inv_spp = (float)1.0f / (float)(progressive ? spp * (int)(frame_index + 1) : spp);
             rp.rgba = d_rgba; rp.accum = d_accum;
@@ -285,20 +399,21 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
         }
     }
 
-    if (progressive) g.prog_frames++;
+    if (progressive) g.prog_frames = frames_after;
 
     if (o.stats) {
         st.samples = (uint64_t)npix * (uint64_t)spp;
         st.chunk_spp = (uint32_t)chunk;
         if (npix > 0 && max_depth > 0) {
-            unsigned long long c[8] = {0};
-            HIP_TRY(hipMemcpy(c, g.counters.p, sizeof c, hipMemcpyDeviceToHost));
+            unsigned long long *c = g.last_counters;
+            HIP_TRY(hipMemcpy(c, d_counters, sizeof g.last_counters, hipMemcpyDeviceToHost));
             st.rays = c[1];
 #ifdef RT_DIAG
             fprintf(stderr, "diag: wave scans %llu; per wave scan: pair branches taken %.1f, filter passes %.1f, "
-                    "queued candidates %.2f, drain iterations %.2f, live lanes %.1f; rays traced in shared-ray mode %llu of %llu\n",
+                    "queued candidates %.2f, drain iterations %.2f, live lanes %.1f; rays traced in shared-ray mode %llu of %llu; "
+                    "rays whose nearest hit differs from the all-spheres exact test: %llu\n",
                     c[5], (double)c[2] / c[5], (double)c[7] / c[5], (double)c[3] / c[5], (double)c[4] / c[5],
-                    (double)(c[6] & ((1ULL << 40) - 1)) / c[5], c[6] >> 40, c[1]);
+                    (double)(c[6] & ((1ULL << 40) - 1)) / c[5], c[6] >> 40, c[1], c[8]);
 #endif
             st.sphere_tests = c[1] * (uint64_t)g.n;
             float ms = 0.0f;
@@ -313,13 +428,7 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
     return RT_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-const char *rt_last_error(void) { return g_err; }
-
-static void release_ctx(Ctx &g)
+void release_ctx(Ctx &g)
 {
     if (!g.inited) return;
     (void)hipSetDevice(g.device);
@@ -333,7 +442,7 @@ static void release_ctx(Ctx &g)
     g = Ctx();
 }
 
-static int init_ctx(Ctx &g, int device, int count)
+int init_ctx(Ctx &g, int device, int count)
 {
     if (device < 0 || device >= count) return fail(RT_ERR_ARG, "rt_init: device %d outside [0,%d)", device, count);
     HIP_TRY(hipSetDevice(device));
@@ -348,33 +457,202 @@ static int init_ctx(Ctx &g, int device, int count)
     HIP_TRY(hipEventCreate(&g.ev0));
     HIP_TRY(hipEventCreate(&g.ev1));
     HIP_TRY(hipEventCreate(&g.ev2));
-    HIP_TRY(g.counters.reserve(8 * sizeof(unsigned long long)));
+    HIP_TRY(g.counters.reserve(kScratchCountersBytes));
     return RT_OK;
 }
 
+void shutdown_all()
+{
+    g_workers.clear();                    // joins the worker threads
+    for (int i = 0; i < kMaxContexts; i++) release_ctx(g_ctx[i]);
+    g_nctx = 0;
+}
+
+// Several contexts: the rows this call owns (all rows, the caller's part, or the caller's row list)
+// are dealt in tiles to the contexts in proportion to the speed each showed in the previous frame
+// (smooth weighted round robin: every context's tiles stay spread over the image), one host thread
+// per context renders its rows into the caller's buffers.  The image does not depend on the deal:
+// the unit size is resolved once, from the full image, for all contexts.
+// Progressive frames keep the deal of frame 0 (each context carries the running sums of its rows).
+std::vector<std::vector<uint32_t>> g_prog_rows;      // the deal of frame 0
+std::vector<uint32_t> g_prog_mine;                   // the rows the caller owned in frame 0
+
+int render_on_all(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height, int spp,
+                  int max_depth, const rt_opts *opts, int chunk, int64_t frame_index = -1)
+{
+    using clk = std::chrono::steady_clock;
+    const auto t_start = clk::now();
+    rt_opts base;
+    memset(&base, 0, sizeof base);
+    if (opts) base = *opts;
+    if (base.tile_rows < 0) return fail(RT_ERR_ARG, "rt_render: negative tile_rows");
+    const int tile_rows = base.tile_rows > 0 ? base.tile_rows : 16;
+    const int part_count = base.part_count > 1 ? base.part_count : 1;
+    const int part_index = part_count > 1 ? base.part_index : 0;
+    if (part_index < 0 || part_index >= part_count) return fail(RT_ERR_ARG, "rt_render: part_index %d outside [0,%d)", base.part_index, part_count);
+    std::vector<uint32_t> mine;
+    if (base.rows) {
+        for (uint32_t k = 0; k < base.row_count; k++) {
+            if (base.rows[k] >= height || (k > 0 && base.rows[k] <= base.rows[k - 1]))
+                return fail(RT_ERR_ARG, "rt_render: rows[] must be strictly ascending and below the image height (entry %u)", k);
+            mine.push_back(base.rows[k]);
+        }
+    } else {
+        const uint32_t n = rt_part_rows(height, tile_rows, part_index, part_count);
+        for (uint32_t k = 0; k < n; k++) mine.push_back(rt_part_row_at(k, tile_rows, part_index, part_count));
+    }
+    const int nc = g_nctx;
+    const bool progressive = frame_index >= 0;
+    auto end_sequence = [&]() {
+        for (int i = 0; i < nc; i++) g_ctx[i].prog_frames = kProgBroken;
+        g_prog_rows.clear();
+        g_prog_mine.clear();
+    };
+    std::vector<std::vector<uint32_t>> rows(nc);
+    if (progressive && frame_index > 0) {
+        if ((int)g_prog_rows.size() != nc || g_prog_mine != mine) {
+            end_sequence();
+            return fail(RT_ERR_STATE, "rt_render_progressive: frame %lld does not own the rows frame 0 owned; start again with frame_index 0",
+                        (long long)frame_index);
+        }
+        rows = g_prog_rows;
+    } else {
+        double wsum = 0.0;
+        for (int i = 0; i < nc; i++) wsum += g_ctx[i].speed;
+        std::vector<double> credit(nc, 0.0);
+        const size_t deal_rows = 2;                           // fine tiles: the split follows the weights closely
+        for (size_t t = 0; t < mine.size(); t += deal_rows) {
+            int best = 0;
+            for (int i = 0; i < nc; i++) {
+                credit[i] += g_ctx[i].speed / wsum;
+                if (credit[i] > credit[best] + 1e-12) best = i;
+            }
+            credit[best] -= 1.0;
+            for (size_t k = t; k < std::min(mine.size(), t + deal_rows); k++) rows[best].push_back(mine[k]);
+        }
+        if (progressive) { g_prog_rows = rows; g_prog_mine = mine; }
+    }
+
+    std::vector<rt_stats> st(nc);
+    std::vector<int> rc(nc, RT_OK);
+    std::vector<std::string> msg(nc);
+    for (int i = 0; i < nc; i++) memset(&st[i], 0, sizeof(rt_stats));
+    Call call;
+    call.chunk = chunk;
+    call.frame_index = frame_index;
+    auto work = [&](int i) {
+        if (rows[i].empty()) return;                     // fewer tiles than contexts
+        rc[i] = guarded("rt_render", [&]() {
+            rt_opts o = base;
+            o.rows = rows[i].data();
+            o.row_count = (uint32_t)rows[i].size();
+            o.stats = &st[i];
+            return render_common(g_ctx[i], cam, rgba, width, height, spp, max_depth, &o, call);
+        });
+        if (rc[i] != RT_OK) { try { msg[i] = g_err; } catch (...) {} }
+    };
+    {
+        // whatever happens below, every started worker has finished before the locals it uses go away
+        struct Joiner {
+            int started = 0;
+            ~Joiner() { for (int i = 0; i < started; i++) g_workers[i]->wait(); }
+        } joiner;
+        for (int i = 1; i < nc; i++) {
+            g_workers[i - 1]->start([&work, i] { work(i); });
+            joiner.started = i;
+        }
+        work(0);
+    }
+    for (int i = 0; i < nc; i++)
+        if (rc[i] != RT_OK) {
+            if (progressive) end_sequence();             // the other contexts have already added this frame
+            return fail(rc[i], "device %d: %s", g_ctx[i].device, msg[i].c_str());
+        }
+
+    rt_stats total;
+    memset(&total, 0, sizeof total);
+    total.chunk_spp = (uint32_t)chunk;
+    for (int i = 0; i < nc; i++) {
+        total.samples += st[i].samples; total.rays += st[i].rays; total.sphere_tests += st[i].sphere_tests;
+        total.kernel_ms = std::max(total.kernel_ms, st[i].kernel_ms);
+        total.resolve_ms = std::max(total.resolve_ms, st[i].resolve_ms);
+        if (st[i].kernel_ms > 0.0 && !rows[i].empty())
+            g_ctx[i].speed = (double)rows[i].size() / st[i].kernel_ms;
+    }
+    // keep the weights comparable and no context starved by one odd timing
+    double mean = 0.0;
+    for (int i = 0; i < nc; i++) mean += g_ctx[i].speed / nc;
+    for (int i = 0; i < nc; i++) g_ctx[i].speed = std::min(1.33, std::max(0.75, g_ctx[i].speed / mean));
+    total.total_ms = std::chrono::duration<double, std::milli>(clk::now() - t_start).count();
+    if (base.stats) *base.stats = total;
+    return RT_OK;
+}
+
+// Common front of the render entry points: state and argument checks that must precede the choice of
+// the unit size, then the single- or multi-context path.
+int render_entry(const char *name, const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height, int spp,
+                 int max_depth, const rt_opts *opts, bool device_ptrs, int64_t frame_index)
+{
+    if (g_nctx == 0) return fail(RT_ERR_STATE, "%s: rt_init has not been called", name);
+    if (device_ptrs && g_nctx > 1)
+        return fail(RT_ERR_STATE, "%s: device buffers belong to one device; the library was opened on %d", name, g_nctx);
+    if (width == 0 || height == 0 || (uint64_t)width * height > 0x7fffffffULL)
+        return fail(RT_ERR_ARG, "%s: bad image size %ux%u", name, width, height);
+    if (spp < 1) return fail(RT_ERR_ARG, "%s: spp must be >= 1 (got %d)", name, spp);
+    const int chunk_opt = opts ? opts->chunk_spp : RT_CHUNK_AUTO;
+    if (chunk_opt < 0 && chunk_opt != RT_CHUNK_AUTO) return fail(RT_ERR_ARG, "%s: negative chunk_spp", name);
+    DeviceGuard keep;
+    const int chunk = resolve_chunk(chunk_opt, width, height, spp, frame_index >= 0);
+    if (g_nctx > 1) return render_on_all(cam, rgba, width, height, spp, max_depth, opts, chunk, frame_index);
+    Call call;
+    call.device_ptrs = device_ptrs;
+    call.frame_index = frame_index;
+    call.chunk = chunk;
+    return render_common(g_ctx[0], cam, rgba, width, height, spp, max_depth, opts, call);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_err; }
+
 int rt_init_devices(const int *devices, int count)
 {
-    rt_shutdown();
-    if (!devices || count < 1 || count > kMaxContexts)
-        return fail(RT_ERR_ARG, "rt_init_devices: between 1 and %d devices (got %d)", kMaxContexts, count);
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev <= 0) return fail(RT_ERR_DEVICE, "rt_init: no HIP device (%s)", hipGetErrorString(e));
-    for (int i = 0; i < count; i++) {
-        const int rc = init_ctx(g_ctx[i], devices[i], ndev);
-        if (rc != RT_OK) {
-            for (int k = 0; k <= i; k++) release_ctx(g_ctx[k]);
-            return rc;
+    return guarded("rt_init", [&]() -> int {
+        DeviceGuard keep;
+        shutdown_all();
+        if (!devices || count < 1 || count > kMaxContexts)
+            return fail(RT_ERR_ARG, "rt_init_devices: between 1 and %d devices (got %d)", kMaxContexts, count);
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0) {
+            (void)hipGetLastError();
+            return fail(RT_ERR_DEVICE, "rt_init: no HIP device (%s)", hipGetErrorString(e));
         }
-    }
-    g_nctx = count;
-    g_err[0] = 0;
-    return RT_OK;
+        for (int i = 0; i < count; i++) {
+            const int rc = init_ctx(g_ctx[i], devices[i], ndev);
+            if (rc != RT_OK) {
+                for (int k = 0; k <= i; k++) release_ctx(g_ctx[k]);
+                return rc;
+            }
+        }
+        try {
+            for (int i = 1; i < count; i++) g_workers.emplace_back(new Worker());
+        } catch (...) {
+            g_workers.clear();
+            for (int k = 0; k < count; k++) release_ctx(g_ctx[k]);
+            return fail(RT_ERR_NOMEM, "rt_init_devices: cannot start the per-device host threads");
+        }
+        g_nctx = count;
+        g_err[0] = 0;
+        return RT_OK;
+    });
 }
 
 int rt_init(int device) { return rt_init_devices(&device, 1); }
 
-int rt_set_world(const rt_sphere *spheres, size_t count)
+static int set_world_impl(const rt_sphere *spheres, size_t count)
 {
     if (g_nctx == 0) return fail(RT_ERR_STATE, "rt_set_world: rt_init has not been called");
     if (!spheres && count) return fail(RT_ERR_ARG, "rt_set_world: null sphere array");
@@ -383,6 +661,7 @@ int rt_set_world(const rt_sphere *spheres, size_t count)
     for (size_t i = 0; i < count; i++)
         if (spheres[i].mat_type < RT_MAT_LAMBERTIAN || spheres[i].mat_type > RT_MAT_DIELECTRIC)
             return fail(RT_ERR_ARG, "rt_set_world: sphere %zu has unsupported material type %d", i, spheres[i].mat_type);
+    DeviceGuard keep;
     const int n = (int)count;
     const int n_pad = n == 0 ? kGeomPad : ((n + kGeomPad - 1) / kGeomPad) * kGeomPad;
     std::vector<float4> geom(n_pad), matA(n > 0 ? n : 1), matB(n > 0 ? n : 1);
@@ -399,7 +678,7 @@ int rt_set_world(const rt_sphere *spheres, size_t count)
             geom[i] = make_float4(0.0f, 0.0f, 0.0f, -std::numeric_limits<float>::infinity());
         }
     }
-    // Fast build's filter data.  A sphere is "big" when its extent |C| + r exceeds four times the
+    // Filter data.  A sphere is "big" when its extent |C| + r exceeds four times the
     // median extent (at most kMaxBig of them, the largest first).
     std::vector<double> extent(n > 0 ? n : 1, 0.0);
     for (int i = 0; i < n; i++) {
@@ -435,6 +714,7 @@ int rt_set_world(const rt_sphere *spheres, size_t count)
     for (int k = 0; k < g_nctx; k++) {
         Ctx &g = g_ctx[k];
         HIP_TRY(hipSetDevice(g.device));
+        HIP_TRY(hipStreamSynchronize(g.stream));
         HIP_TRY(g.pairs.reserve(pairs.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(g.pairs.p, pairs.data(), pairs.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(g.geom.reserve(geom.size() * sizeof(float4)));
@@ -448,122 +728,47 @@ int rt_set_world(const rt_sphere *spheres, size_t count)
         g.nbig = nbig;
         memcpy(g.big, big, sizeof big);
         g.c_near = (float)c_near;
+        // Look up the launch geometry of both builds now (code objects load, LDS attributes are set,
+        // occupancy is queried), so that no render call after this one has to.
+        const bool geom_global = n > kMaxSpheresLds;
+        for (int strict = 0; strict < 2; strict++) {
+            const size_t lds = (geom_global ? 0 : (size_t)n_pad * sizeof(float4)) +
+                               (size_t)queue_lds_bytes(kBlockThreads, strict ? kQueueSlotsStrict : kQueueSlotsFast);
+            for (int mode = 0; mode < 2; mode++)
+                HIP_TRY(strict ? prepare_trace_strict(g.launch, mode, geom_global, lds) : prepare_trace_fast(g.launch, mode, geom_global, lds));
+            (void)(strict ? trace_blocks_per_cu_strict(g.launch, geom_global, lds) : trace_blocks_per_cu_fast(g.launch, geom_global, lds));
+        }
     }
     return RT_OK;
 }
 
-// Several contexts: the rows this call owns (all rows, the caller's part, or the caller's row list)
-// are dealt in tiles to the contexts in proportion to the speed each showed in the previous frame
-// (smooth weighted round robin: every context's tiles stay spread over the image), one host thread
-// per context renders its rows into the caller's buffers.  The image does not depend on the deal.
-// Progressive frames keep the deal of frame 0 (each context carries the running sums of its rows).
-static std::vector<std::vector<uint32_t>> g_prog_rows;
-
-static int render_on_all(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height, int spp,
-                         int max_depth, const rt_opts *opts, int64_t frame_index = -1)
+int rt_set_world(const rt_sphere *spheres, size_t count)
 {
-    using clk = std::chrono::steady_clock;
-    const auto t_start = clk::now();
-    rt_opts base;
-    memset(&base, 0, sizeof base);
-    if (opts) base = *opts; else base.chunk_spp = RT_CHUNK_AUTO;
-    if (height == 0 || width == 0) return fail(RT_ERR_ARG, "rt_render: bad image size %ux%u", width, height);
-    const int tile_rows = base.tile_rows > 0 ? base.tile_rows : 16;
-    const int part_count = base.part_count > 1 ? base.part_count : 1;
-    const int part_index = part_count > 1 ? base.part_index : 0;
-    if (part_index < 0 || part_index >= part_count) return fail(RT_ERR_ARG, "rt_render: part_index %d outside [0,%d)", base.part_index, part_count);
-    std::vector<uint32_t> mine;
-    if (base.rows) {
-        for (uint32_t k = 0; k < base.row_count; k++) {
-            if (base.rows[k] >= height || (k > 0 && base.rows[k] <= base.rows[k - 1]))
-                return fail(RT_ERR_ARG, "rt_render: rows[] must be strictly ascending and below the image height (entry %u)", k);
-            mine.push_back(base.rows[k]);
-        }
-    } else {
-        const uint32_t n = rt_part_rows(height, tile_rows, part_index, part_count);
-        for (uint32_t k = 0; k < n; k++) mine.push_back(rt_part_row_at(k, tile_rows, part_index, part_count));
-    }
-    const int nc = g_nctx;
-    double wsum = 0.0;
-    for (int i = 0; i < nc; i++) wsum += g_ctx[i].speed;
-    std::vector<double> credit(nc, 0.0);
-    std::vector<std::vector<uint32_t>> rows(nc);
-    const int deal_rows = 2;                                  // fine tiles: the split follows the weights closely
-    const bool reuse_deal = frame_index > 0 && (int)g_prog_rows.size() == nc;
-    if (reuse_deal) rows = g_prog_rows;
-    for (size_t t = 0; !reuse_deal && t < mine.size(); t += deal_rows) {
-        int best = 0;
-        for (int i = 0; i < nc; i++) {
-            credit[i] += g_ctx[i].speed / wsum;
-            if (credit[i] > credit[best] + 1e-12) best = i;
-        }
-        credit[best] -= 1.0;
-        for (size_t k = t; k < std::min(mine.size(), t + deal_rows); k++) rows[best].push_back(mine[k]);
-    }
-
-    if (frame_index == 0) g_prog_rows = rows;
-
-    std::vector<rt_stats> st(nc);
-    std::vector<int> rc(nc, RT_OK);
-    std::vector<std::string> msg(nc);
-    for (int i = 0; i < nc; i++) memset(&st[i], 0, sizeof(rt_stats));
-    auto work = [&](int i) {
-        if (rows[i].empty()) return;                     // fewer tiles than contexts
-        rt_opts o = base;
-        o.rows = rows[i].data();
-        o.row_count = (uint32_t)rows[i].size();
-        o.stats = &st[i];
-        rc[i] = render_common(g_ctx[i], cam, rgba, width, height, spp, max_depth, &o, false, frame_index);
-        if (rc[i] != RT_OK) msg[i] = g_err;
-    };
-    std::vector<std::thread> th;
-    for (int i = 1; i < nc; i++) if (!rows[i].empty()) th.emplace_back(work, i);
-    work(0);
-    for (auto &t : th) t.join();
-    for (int i = 0; i < nc; i++)
-        if (rc[i] != RT_OK) return fail(rc[i], "device %d: %s", g_ctx[i].device, msg[i].c_str());
-
-    rt_stats total;
-    memset(&total, 0, sizeof total);
-    for (int i = 0; i < nc; i++) {
-        total.samples += st[i].samples; total.rays += st[i].rays; total.sphere_tests += st[i].sphere_tests;
-        total.kernel_ms = std::max(total.kernel_ms, st[i].kernel_ms);
-        total.resolve_ms = std::max(total.resolve_ms, st[i].resolve_ms);
-        total.chunk_spp = std::max(total.chunk_spp, st[i].chunk_spp);
-        if (st[i].kernel_ms > 0.0 && !rows[i].empty())
-            g_ctx[i].speed = (double)rows[i].size() / st[i].kernel_ms;
-    }
-    // keep the weights comparable and no context starved by one odd timing
-    double mean = 0.0;
-    for (int i = 0; i < nc; i++) mean += g_ctx[i].speed / nc;
-    for (int i = 0; i < nc; i++) g_ctx[i].speed = std::min(1.33, std::max(0.75, g_ctx[i].speed / mean));
-    total.total_ms = std::chrono::duration<double, std::milli>(clk::now() - t_start).count();
-    if (base.stats) *base.stats = total;
-    return RT_OK;
+    return guarded("rt_set_world", [&]() { return set_world_impl(spheres, count); });
 }
 
 int rt_render(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height, int spp, int max_depth,
               const rt_opts *opts)
 {
-    if (g_nctx == 0) return fail(RT_ERR_STATE, "rt_render: rt_init has not been called");
-    if (g_nctx > 1) return render_on_all(cam, rgba, width, height, spp, max_depth, opts);
-    return render_common(g_ctx[0], cam, rgba, width, height, spp, max_depth, opts, false);
+    return guarded("rt_render", [&]() {
+        return render_entry("rt_render", cam, rgba, width, height, spp, max_depth, opts, false, -1);
+    });
 }
 
 int rt_render_device(const rt_camera *cam, uint8_t *rgba_dev, uint32_t width, uint32_t height, int spp,
                      int max_depth, const rt_opts *opts)
 {
-    if (g_nctx == 0) return fail(RT_ERR_STATE, "rt_render: rt_init has not been called");
-    if (g_nctx > 1) return fail(RT_ERR_STATE, "rt_render_device: device buffers belong to one device; the library was opened on %d", g_nctx);
-    return render_common(g_ctx[0], cam, rgba_dev, width, height, spp, max_depth, opts, true);
+    return guarded("rt_render_device", [&]() {
+        return render_entry("rt_render_device", cam, rgba_dev, width, height, spp, max_depth, opts, true, -1);
+    });
 }
 
 int rt_render_progressive(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height, int spp,
                           int max_depth, const rt_opts *opts, uint32_t frame_index)
 {
-    if (g_nctx == 0) return fail(RT_ERR_STATE, "rt_render: rt_init has not been called");
-    if (g_nctx > 1) return render_on_all(cam, rgba, width, height, spp, max_depth, opts, (int64_t)frame_index);
-    return render_common(g_ctx[0], cam, rgba, width, height, spp, max_depth, opts, false, (int64_t)frame_index);
+    return guarded("rt_render_progressive", [&]() {
+        return render_entry("rt_render_progressive", cam, rgba, width, height, spp, max_depth, opts, false, (int64_t)frame_index);
+    });
 }
 
 uint32_t rt_part_rows(uint32_t height, int tile_rows, int part_index, int part_count)
@@ -583,6 +788,12 @@ uint32_t rt_part_rows(uint32_t height, int tile_rows, int part_index, int part_c
 uint32_t rt_part_row_at(uint32_t k, int tile_rows, int part_index, int part_count)
 {
     return part_row_at(k, tile_rows > 0 ? tile_rows : 16, part_index, part_count > 1 ? part_count : 1);
+}
+
+int rt_chunk_for(uint32_t width, uint32_t height, int spp, int chunk_spp, int progressive)
+{
+    if (width == 0 || height == 0 || spp < 1 || (chunk_spp < 0 && chunk_spp != RT_CHUNK_AUTO)) return 0;
+    return resolve_chunk(chunk_spp, width, height, spp, progressive != 0);
 }
 
 void rt_camera_defaults(rt_camera_params *p)
@@ -681,6 +892,7 @@ int rt_scene_generate(int half_extent, uint32_t lcg_seed, rt_sphere *out, size_t
 void *rt_host_alloc(size_t bytes)
 {
     if (g_nctx == 0) { fail(RT_ERR_STATE, "rt_host_alloc: rt_init has not been called"); return nullptr; }
+    DeviceGuard keep;
     void *p = nullptr;
     if (hipSetDevice(g_ctx[0].device) != hipSuccess || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
         (void)hipGetLastError();
@@ -697,9 +909,24 @@ void rt_host_free(void *ptr)
 
 void rt_shutdown(void)
 {
-    g_prog_rows.clear();
-    for (int i = 0; i < kMaxContexts; i++) release_ctx(g_ctx[i]);
-    g_nctx = 0;
+    (void)guarded("rt_shutdown", [&]() -> int {
+        DeviceGuard keep;
+        g_prog_rows.clear();
+        g_prog_mine.clear();
+        shutdown_all();
+        return RT_OK;
+    });
 }
+
+#ifdef RT_DIAG
+// Diagnostic library only (not declared in rt.h): the device counters of the last render on
+// context 0.  [1] rays, [2] pair branches taken, [3] queued candidates, [4] drain iterations,
+// [5] wave scans, [7] filter passes, [8] rays whose nearest hit differs from the exact test over
+// all spheres.
+void rt_diag_counters(unsigned long long *out, int n)
+{
+    for (int i = 0; i < n && i < kCounters; i++) out[i] = g_ctx[0].last_counters[i];
+}
+#endif
 
 }  // extern "C"

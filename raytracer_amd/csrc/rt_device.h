@@ -58,7 +58,7 @@ struct TraceParams {
     uint32_t seed, sample_base;
     float4 *partial;                       // [nchunks][npix] per-chunk colour sums
     int32_t *hit_index;                    // [npix] compact, or nullptr
-    unsigned long long *counters;          // [0] next work unit, [1] rays cast
+    unsigned long long *counters;          // [0] next work unit, [1] rays cast ([2..15]: diagnostic build)
     unsigned long long total_units;        // npix * nchunks
 };
 
@@ -101,6 +101,10 @@ struct LaunchCache {
 hipError_t launch_trace_strict(LaunchCache &c, const TraceParams &p, bool geom_global, int blocks, size_t lds_bytes, hipStream_t s);
 hipError_t launch_trace_fast(LaunchCache &c, const TraceParams &p, bool geom_global, int blocks, size_t lds_bytes, hipStream_t s);
 hipError_t launch_resolve(const ResolveParams &p, hipStream_t s);
+// Sets the dynamic-LDS attribute of the kernel instantiation (mode, geom_global) if it differs from
+// the cached one; the first call per instantiation also makes the runtime load its code object.
+hipError_t prepare_trace_strict(LaunchCache &c, int mode, bool geom_global, size_t lds_bytes);
+hipError_t prepare_trace_fast(LaunchCache &c, int mode, bool geom_global, size_t lds_bytes);
 int trace_blocks_per_cu_strict(LaunchCache &c, bool geom_global, size_t lds_bytes);
 int trace_blocks_per_cu_fast(LaunchCache &c, bool geom_global, size_t lds_bytes);
 

@@ -243,7 +243,7 @@ __device__ __forceinline__ void exact_test(const float4 *s_geom, int i, Probe &q
 
 #ifdef RT_DIAG
 // Diagnostic build only: where the non-scan instructions go.
-struct Diag { uint32_t branches, passes, drain_iters, drain_lanes, scans, scan_lanes, shared_rays; };
+struct Diag { uint32_t branches, passes, drain_iters, drain_lanes, scans, scan_lanes, shared_rays, lost_hits; };
 #define RT_DIAG_ARG , Diag &dg
 #define RT_DIAG_PASS , dg
 #else
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(cons
     pool_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_next);       // wave-uniform by construction
     pool_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_end);
 #ifdef RT_DIAG
-    Diag dg = {0, 0, 0, 0, 0, 0, 0};
+    Diag dg = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
     for (;;) {
@@ -572,6 +572,20 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(cons
         if (__popcll(live) <= p.coop_max) dg.shared_rays += (uint32_t)__popcll(live); else dg.scan_lanes += (uint32_t)__popcll(live);
 #endif
         if (L.zero_dir) q.hit = -1;
+#endif
+#ifdef RT_DIAG
+        {
+            // Diagnostic build: the exact test over ALL spheres, in index order, must agree with what
+            // the filter, the queues and the drain (or the shared-ray search) found for this ray.
+            Probe all = q;
+            all.closest = 3.402823466e+38f;
+            all.hit = -1;
+            for (int i = 0; i < p.n; i++) exact_test(s_geom, i, all);
+#if !RT_STRICT
+            if (L.zero_dir) all.hit = -1;
+#endif
+            if (active && (all.hit != q.hit || (all.hit >= 0 && all.closest != q.closest))) dg.lost_hits++;
+        }
 #endif
         const float closest = q.closest;
         const int hit = q.hit;
@@ -696,6 +710,11 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(cons
         atomicAdd(&p.counters[5], (unsigned long long)dg.scans);
         atomicAdd(&p.counters[7], (unsigned long long)dg.passes);
         atomicAdd(&p.counters[6], ((unsigned long long)dg.shared_rays << 40) | (unsigned long long)dg.scan_lanes);
+    }
+    {
+        unsigned long long lost = dg.lost_hits;
+        for (int off = 32; off > 0; off >>= 1) lost += __shfl_down(lost, off);
+        if (__lane_id() == 0 && lost != 0ULL) atomicAdd(&p.counters[8], lost);
     }
 #endif
 }

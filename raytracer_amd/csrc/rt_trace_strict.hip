@@ -57,8 +57,9 @@ static trace_fn kernel_for(int mode, bool geom_global)
     return mode ? strict_build::trace_kernel<1, false> : strict_build::trace_kernel<0, false>;
 }
 
-static hipError_t prepare(LaunchCache &c, int mode, bool geom_global, size_t lds_bytes)
+hipError_t prepare_trace_strict(LaunchCache &c, int mode, bool geom_global, size_t lds_bytes)
 {
+    mode = mode == 1 ? 1 : 0;
     if (c.attr_lds[0][mode][geom_global] == lds_bytes) return hipSuccess;
     hipError_t e = hipFuncSetAttribute((const void *)kernel_for(mode, geom_global),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -69,7 +70,7 @@ static hipError_t prepare(LaunchCache &c, int mode, bool geom_global, size_t lds
 hipError_t launch_trace_strict(LaunchCache &c, const TraceParams &p, bool geom_global, int blocks, size_t lds_bytes, hipStream_t s)
 {
     const int mode = p.mode == 1 ? 1 : 0;
-    hipError_t e = prepare(c, mode, geom_global, lds_bytes);
+    hipError_t e = prepare_trace_strict(c, mode, geom_global, lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel_for(mode, geom_global), dim3(blocks), dim3(kBlockThreads), lds_bytes, s, p);
     return hipGetLastError();
@@ -79,7 +80,7 @@ int trace_blocks_per_cu_strict(LaunchCache &c, bool geom_global, size_t lds_byte
 {
     if (c.occ_lds[0][geom_global] == lds_bytes) return c.occ_blocks[0][geom_global];
     int n = 0;
-    if (prepare(c, 0, geom_global, lds_bytes) != hipSuccess ||
+    if (prepare_trace_strict(c, 0, geom_global, lds_bytes) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel_for(0, geom_global), kBlockThreads, lds_bytes) != hipSuccess)
         return 1;
     c.occ_lds[0][geom_global] = lds_bytes;

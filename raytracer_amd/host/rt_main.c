@@ -137,8 +137,8 @@ int main(int argc, char **argv)
         rc = (len > 4 && !strcmp(out + len - 4, ".tga")) ? write_tga(out, rgba, width, height)
                                                          : write_ppm(out, rgba, width, height);
     }
+    if (rgba_locked) rt_host_free(rgba); else free(rgba);      /* page-locked memory goes back while the library is open */
     rt_shutdown();
-    if (rgba_locked) rt_host_free(rgba); else free(rgba);
     free(spheres);
     return rc ? 1 : 0;
 }
