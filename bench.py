@@ -10,8 +10,14 @@ One process per GPU.  A step = one full frame: every rank path-traces its interl
 tiles with the HIP kernel (through the C ABI, device-resident output), the rows are gathered
 to rank 0 over RCCL and scattered into the full RGBA8 framebuffer on GPU 0.  The image is
 fixed as N grows (strong scaling).  Rank 0 prints one JSON line.
+
+At N = 1 the same run also reports, after the timed loop: the bit-reproducible (strict) build on the
+same workload, the rate with the read-back of every frame into page-locked host memory included
+(rt_render instead of rt_render_device), and the CPU baseline (the reference's own code on the host).
 """
 import argparse
+import csv
+import glob
 import json
 import os
 import subprocess
@@ -25,22 +31,55 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3      # MI355X vector FP32: 256 CU x 256 flop/clk x 2.4 GHz
-FLOP_PER_TEST = 18            # hit_sphere's miss path (Main.c:628-654) with |d|^2 hoisted per ray
+FLOP_PER_TEST = 18            # ALGORITHMIC: hit_sphere's miss path (Main.c:628-654) with |d|^2 hoisted per ray
+EXECUTED_FLOP_PER_TEST = 14   # what the filter scan executes: 7 packed FMAs per pair of spheres
+
+PARITY_BAR = {
+    "fast": "deterministic output; PSNR >= 40 dB against the reference's converged render (tests: 52.6 dB 3-sphere, "
+            "48.2 dB final scene); every ray's nearest hit equals the exact test over all spheres (diagnostic build)",
+    "strict": "bit-exact: hit indices, f32 accumulators, RGBA8 bytes and ray counts equal the CPU restatement of the "
+              "reference run with the same counter generator; deterministic mode equals the compiled reference",
+}
 
 
-def cpu_baseline(width, spp, depth, threads):
+def host_cores():
+    """(cores the host reports, cores this job may use).  The reference sizes its thread pool from
+    get_core_count() = sysconf(_SC_NPROCESSORS_ONLN) (src/util.c:512-520); a job confined to a share of
+    a large host (affinity mask, or the share the launcher states in OMP_NUM_THREADS) must not start
+    two threads per core of the whole machine."""
+    reported = os.cpu_count() or 1
+    usable = reported
+    try:
+        usable = min(usable, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        share = int(os.environ.get("OMP_NUM_THREADS", "0"))
+        if share > 0:
+            usable = min(usable, share)
+    except ValueError:
+        pass
+    return reported, max(1, usable)
+
+
+def cpu_baseline(width, spp, depth, threads=0):
     """The reference's own code (oracle/_ref, built from /root/reference in the build container)
-    timed on this host; falls back to the CPU port when that binary did not travel."""
+    timed on this host in the reference's threading shape: 64x64 tiles, one OS thread per tile,
+    2 x cores thread slots, slot i % T joined before reuse (Main.c:1002-1054).  Falls back to the CPU
+    port (a tile pool of the same size) when that binary did not travel."""
     from oracle import refcpu as rc
+    reported, usable = host_cores()
+    if threads <= 0:
+        threads = 2 * usable                                          # Main.c:1002
     height = rc.height_for(width)
     samples = width * height * spp
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness_sf")
-    sample = "final scene %dx%d, %d spp (of 1000), depth %d, %d threads over 64x64 tiles" % (
-        width, height, spp, depth, threads)
+    sample = ("final scene %dx%d, %d spp (of 1000), depth %d; %d thread slots = 2 x the %d cores this job may use "
+              "(the host reports %d), one thread per 64x64 tile" % (width, height, spp, depth, threads, usable, reported))
     if os.path.exists(exe):
         with tempfile.NamedTemporaryFile(suffix=".rgba") as f:
             t0 = time.perf_counter()
-            subprocess.check_call([exe, "mc", str(width), str(spp), str(depth), f.name, str(threads)],
+            subprocess.check_call([exe, "mcref", str(width), str(spp), str(depth), f.name, str(threads)],
                                   stderr=subprocess.DEVNULL)
             dt = time.perf_counter() - t0
         kind = "reference"
@@ -52,7 +91,65 @@ def cpu_baseline(width, spp, depth, threads):
         dt = time.perf_counter() - t0
         kind = "port"
     return {"value": round(samples / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": kind,
+            "host_cores": reported, "usable_cores": usable, "threads": threads,
             "sample": sample, "seconds": round(dt, 2)}
+
+
+def measured_traffic(kernel_substr, workload_key):
+    """HBM bytes per launch of the path-tracing kernel from the newest committed rocprofv3 --pmc
+    passes (profiles/<round>/pmc_fetch.csv + pmc_write.csv, each its own run of this command):
+    Counter_Value is in KiB; FETCH_SIZE is doubled (on gfx950 it tallies 128-byte requests as 64).
+    None if no pass for this workload is on file (profiles/<round>/pmc_workload.txt names it)."""
+    best = None
+    for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "*"))):
+        fw, ff, fk = (os.path.join(d, n) for n in ("pmc_write.csv", "pmc_fetch.csv", "pmc_workload.txt"))
+        if not (os.path.exists(fw) and os.path.exists(ff) and os.path.exists(fk)):
+            continue
+        if open(fk).read().strip() != workload_key:
+            continue
+        tot = {}
+        for path, name, scale in ((fw, "WRITE_SIZE", 1024.0), (ff, "FETCH_SIZE", 2048.0)):
+            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+                    if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == name]
+            if not vals:
+                tot = None
+                break
+            tot[name] = scale * sum(vals) / len(vals)
+        if tot:
+            best = {"bytes": tot["WRITE_SIZE"] + tot["FETCH_SIZE"], "write": tot["WRITE_SIZE"], "fetch": tot["FETCH_SIZE"],
+                    "source": os.path.relpath(d, ROOT)}
+    return best
+
+
+class MockRt:
+    """--mock: stands in for the library so that the N > 1 plumbing and the JSON line can be checked
+    on a machine without a GPU (tests only; the line says "mock": true and measures nothing)."""
+    SPHERE_DTYPE = np.dtype([("center", "<f4", 3), ("radius", "<f4"), ("mat_type", "<i4"),
+                             ("albedo", "<f4", 3), ("fuzz", "<f4"), ("ior", "<f4")])
+
+    class _St:
+        pass
+
+    def __init__(self, torch):
+        self.torch = torch
+        self.buffers = {}
+
+    def init(self, dev): pass
+    def set_world(self, sph): self.n = len(sph)
+    def shutdown(self): pass
+    def height_for(self, w): return int(np.float32(w) / np.float32(16.0 / 9.0))
+    def camera(self, w, h): return None
+    def chunk_for(self, w, h, spp, chunk=-1, progressive=False): return 8 if chunk < 0 else (chunk or spp)
+
+    def render_device(self, cam, ptr, W, H, spp, depth, rows=None, chunk_spp=-1, **kw):
+        self.buffers[ptr][:len(rows)] = 255
+        st = self._St()
+        st.samples = len(rows) * W * spp
+        st.rays = 3 * st.samples
+        st.sphere_tests = st.rays * self.n
+        st.kernel_ms = 1.0 + 0.001 * len(rows)
+        st.chunk_spp = self.chunk_for(W, H, spp, chunk_spp)
+        return st
 
 
 def main():
@@ -64,23 +161,31 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--spp", type=int, default=1000)
     ap.add_argument("--depth", type=int, default=50)
-    ap.add_argument("--chunk", type=int, default=-1, help="samples per work unit (-1: the library chooses)")
+    ap.add_argument("--chunk", type=int, default=-1, help="samples per work unit (-1: the library chooses, from the full image size and spp)")
     ap.add_argument("--tile-rows", type=int, default=2, help="rows per dealt tile: small tiles keep the deal fine-grained (2160 rows over 8 ranks)")
-    ap.add_argument("--strict", type=int, default=0, help="1 = bit-reproducible build (no FMA)")
+    ap.add_argument("--strict", type=int, default=0, help="1 = time the bit-reproducible build (no FMA) as the main loop")
+    ap.add_argument("--strict-steps", type=int, default=3, help="N = 1: steps of the strict build after the timed loop (0 = skip)")
+    ap.add_argument("--readback-steps", type=int, default=2, help="N = 1: steps of rt_render into page-locked host memory (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: only the timed loop (no strict / read-back / CPU legs)")
     ap.add_argument("--no-rebalance", action="store_true", help="keep the equal row-tile deal (N > 1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages the gather through host memory (rehearsal only)")
     ap.add_argument("--shared-gpu", action="store_true",
                     help="rehearsal of the N > 1 path on a one-GPU box: every rank uses device 0 (needs --backend gloo)")
+    ap.add_argument("--mock", action="store_true", help="no GPU, no kernel: checks the N > 1 plumbing and the JSON shape (needs --backend gloo)")
+    ap.add_argument("--n1-value", type=float, default=0.0, help="the N = 1 value of the same workload: adds efficiency_vs_n1")
     ap.add_argument("--cpu-width", type=int, default=3840)
     ap.add_argument("--cpu-spp", type=int, default=1)
-    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="thread slots of the CPU leg (0 = 2 x usable cores, the reference's rule)")
     args = ap.parse_args()
+    if args.no_extras:
+        args.strict_steps = 0
+        args.readback_steps = 0
+        args.no_cpu = True
 
     import torch
     import torch.distributed as dist
-    import raytracer_amd as rt
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -88,14 +193,21 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)"
                          % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py: no GPU visible; the HIP path has no CPU fallback")
-    if args.shared_gpu:
+    if args.mock:
         if args.backend != "gloo":
-            raise SystemExit("bench.py: --shared-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+            raise SystemExit("bench.py: --mock needs --backend gloo")
+        rt = MockRt(torch)
+        dev = torch.device("cpu")
+    else:
+        import raytracer_amd as rt
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py: no GPU visible; the HIP path has no CPU fallback")
+        if args.shared_gpu:
+            if args.backend != "gloo":
+                raise SystemExit("bench.py: --shared-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
+            local = 0
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -103,6 +215,7 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     coll_dev = dev if args.backend == "nccl" else torch.device("cpu")     # where small collectives live
+    on_gpu = dev.type == "cuda"
 
     W = args.width
     H = rt.height_for(W)
@@ -110,6 +223,8 @@ def main():
     rt.init(local)
     rt.set_world(sph)
     cam = rt.camera(W, H)
+    # one unit size for all ranks: resolved from the full image, never from a rank's share of it
+    chunk = rt.chunk_for(W, H, args.spp, args.chunk)
 
     from raytracer_amd.multigpu import RowGather, weighted_row_maps
 
@@ -122,23 +237,34 @@ def main():
         part.rows = weighted_row_maps(H, args.tile_rows, part.weights)
         # compact owned rows -> full image on rank 0
         part.rg = RowGather(part.rows, W, 4, torch.uint8, dev, rank, world, via_host=(args.backend == "gloo"))
+        if args.mock:
+            for b in part.rg._send:
+                rt.buffers[b.data_ptr()] = b
 
     deal([1.0] * world)                                            # equal weights = tile t -> rank t % world
+    rows_initial = [int(len(r)) for r in part.rows]
     part.rg.connect()                                              # peer connections exist before anything is timed
 
     def sync():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
-    def step():
+    gather_ms = []
+
+    def step(strict):
         st = rt.render_device(cam, part.rg.mine.data_ptr(), W, H, args.spp, args.depth,
-                              strict_fp=bool(args.strict), seed=0, chunk_spp=args.chunk, rows=part.rows[rank])
+                              strict_fp=bool(strict), seed=0, chunk_spp=chunk, rows=part.rows[rank])
+        t0 = time.perf_counter()
         part.rg.gather()                                              # RCCL over xGMI when world > 1
+        if on_gpu:
+            torch.cuda.synchronize()
+        gather_ms.append((time.perf_counter() - t0) * 1e3)
         return st
 
     for i in range(args.warmup):
-        st = step()
+        st = step(args.strict)
         if world > 1 and not args.no_rebalance and i < max(1, args.warmup - 1):
             # MI355X devices hold different clocks on this compute-bound kernel (10 % apart is
             # common): deal the row tiles in proportion to the speed each rank just showed, so
@@ -150,26 +276,53 @@ def main():
             sp = speed.cpu().numpy()
             med = float(np.median(sp))
             deal(np.clip(sp, 0.75 * med, 1.33 * med).tolist())        # one odd timing must not starve a rank
+    gather_ms.clear()
     sync()
     t0 = time.perf_counter()
-    stats = [step() for _ in range(args.steps)]
+    stats = [step(args.strict) for _ in range(args.steps)]
     sync()
     dt = time.perf_counter() - t0
 
+    kernel_ms = float(np.mean([s.kernel_ms for s in stats]))                 # HIP events on the library's stream
+    per_rank_kernel_ms = [kernel_ms]
+    per_rank_gather_ms = [float(np.mean(gather_ms))]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        k = torch.zeros(2 * world, dtype=torch.float64, device=coll_dev)
+        k[rank] = kernel_ms
+        k[world + rank] = float(np.mean(gather_ms))
+        dist.all_reduce(k, op=dist.ReduceOp.SUM)
+        k = k.cpu().numpy()
+        per_rank_kernel_ms = [round(float(v), 3) for v in k[:world]]
+        per_rank_gather_ms = [round(float(v), 3) for v in k[world:]]
+        # whole-frame statistics: sums over ranks
+        tot = torch.tensor([float(np.mean([s.sphere_tests for s in stats])), float(np.mean([s.rays for s in stats])),
+                            float(np.mean([s.samples for s in stats]))], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        tests_all, rays_all, samples_all = [float(v) for v in tot.cpu().numpy()]
+    else:
+        tests_all = float(np.mean([s.sphere_tests for s in stats]))
+        rays_all = float(np.mean([s.rays for s in stats]))
+        samples_all = float(np.mean([s.samples for s in stats]))
+
+    def roofline_of(tests, ms):
+        achieved = FLOP_PER_TEST * tests / (ms * 1e-3) / 1e12
+        return achieved, achieved / PEAK_FP32_TFLOPS
 
     if rank == 0:
         img = part.rg.full.cpu().numpy()
         assert (img[..., 3] == 255).all(), "framebuffer not fully written"
         samples = W * H * args.spp
-        kernel_ms = float(np.mean([s.kernel_ms for s in stats]))                 # HIP events on the library's stream
-        tests = float(np.mean([s.sphere_tests for s in stats]))
-        rays = float(np.mean([s.rays for s in stats]))
-        own_samples = float(np.mean([s.samples for s in stats]))
-        achieved = FLOP_PER_TEST * tests / (kernel_ms * 1e-3) / 1e12
+        tests = float(np.mean([s.sphere_tests for s in stats]))                  # this rank's launch
+        achieved, frac = roofline_of(tests, kernel_ms)
+        kname = "strict" if args.strict else "fast"
+        workload = "RTIOW %s scene %dx%d, %d spp, depth %d" % (
+            "final" if args.scene == "sf" else "3-sphere", W, H, args.spp, args.depth)
+        traffic = None
+        if world == 1 and not args.mock:
+            traffic = measured_traffic("%s_build::trace_kernel" % kname, "%s, %s build, chunk %d" % (workload, kname, chunk))
         out = {
             "metric": "Msamples/s (px*spp/s) RTIOW final scene" if args.scene == "sf" else "Msamples/s (px*spp/s) 3-sphere scene",
             "value": round(samples * args.steps / dt / 1e6, 3),
@@ -181,29 +334,74 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (the reference's generated %d-sphere scene, committed fixture)" % len(sph),
-            "config": {"workload": "RTIOW %s scene %dx%d, %d spp, depth %d" % (
-                           "final" if args.scene == "sf" else "3-sphere", W, H, args.spp, args.depth),
+            "config": {"workload": workload,
                        "spheres": int(len(sph)), "chunk_spp": int(stats[-1].chunk_spp), "tile_rows": args.tile_rows,
-                       "kernel": "strict" if args.strict else "fast",
+                       "kernel": kname, "parity_bar": PARITY_BAR[kname],
                        "parallelism": "row-tiles x%d, %s gather to rank 0%s" % (
                            world, "RCCL" if args.backend == "nccl" else "gloo (host-staged)",
                            ", all ranks on ONE gpu (rehearsal)" if args.shared_gpu else ""),
                        "rows_per_rank": [int(len(r)) for r in part.rows]},
+            # achieved = ALGORITHMIC flop (18 per ray-sphere test, the reference's formulation) per second
+            # of this rank's kernel; frac = achieved / the vector FP32 peak: a useful-work rate against the
+            # hardware peak.  executed_frac counts what the filter scan really issues (14 flop per test).
             "roofline": {"bound": "valu_fp32", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-                         # HBM bytes per launch of trace_kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-                         # passes on this command (the counter files are kept under profiles/;
-                         # FETCH_SIZE doubled, the gfx950 correction): 2.27 GB written + 0.01-0.2 GB read.
-                         # Only known for the default workload on one GPU, null otherwise
-                         "traffic": (2.3e9 if (world == 1 and W == 3840 and args.spp == 1000
-                                                and int(stats[-1].chunk_spp) == 63 and not args.strict) else None),
+                         "unit": "TFLOP/s", "frac": round(frac, 4),
+                         "numerator": "algorithmic flop (18 per ray-sphere test) / kernel time",
+                         "executed_frac": round(frac * EXECUTED_FLOP_PER_TEST / FLOP_PER_TEST, 4),
+                         "traffic": round(traffic["bytes"]) if traffic else None,
+                         "traffic_source": traffic["source"] if traffic else None,
                          "kernel": "trace_kernel", "kernel_ms": round(kernel_ms, 3),
                          "flop_per_sphere_test": FLOP_PER_TEST,
-                         "sphere_tests_per_launch": tests, "rays_per_sample": round(rays / own_samples, 4)},
-            "kernel_only_msamples_per_s": round(own_samples / kernel_ms / 1e3, 3),
+                         "sphere_tests_per_launch": tests, "rays_per_sample": round(rays_all / samples_all, 4)},
+            "kernel_only_msamples_per_s": round(float(np.mean([s.samples for s in stats])) / kernel_ms / 1e3, 3),
+            "gather_ms": round(per_rank_gather_ms[0], 3),
         }
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_width, args.cpu_spp, args.depth, args.cpu_threads)
+        if args.mock:
+            out["mock"] = True
+        if world > 1:
+            out["backend"] = dist.get_backend()
+            out["dist_world"] = dist.get_world_size()
+            out["kernel_ms_per_rank"] = per_rank_kernel_ms
+            out["gather_ms_per_rank"] = per_rank_gather_ms
+            out["rows_per_rank_initial"] = rows_initial
+            out["rows_per_rank"] = [int(len(r)) for r in part.rows]
+            out["sphere_tests_all_ranks"] = tests_all
+            if args.n1_value > 0:
+                out["efficiency_vs_n1"] = round(out["value"] / (world * args.n1_value), 4)
+        if world == 1 and not args.mock:
+            if args.strict_steps > 0 and not args.strict:
+                step(1)                                                          # warm-up of the strict build
+                sync()
+                t1 = time.perf_counter()
+                sst = [step(1) for _ in range(args.strict_steps)]
+                sync()
+                sdt = time.perf_counter() - t1
+                sk = float(np.mean([s.kernel_ms for s in sst]))
+                sa, sf_ = roofline_of(float(np.mean([s.sphere_tests for s in sst])), sk)
+                out["strict"] = {"value": round(samples * args.strict_steps / sdt / 1e6, 3), "unit": "Msamples/s",
+                                 "steps": args.strict_steps, "kernel_ms": round(sk, 3), "achieved": round(sa, 3),
+                                 "frac": round(sf_, 4), "parity_bar": PARITY_BAR["strict"]}
+            if args.readback_steps > 0:
+                # the metric as a C host sees it: rt_render writes the frame into the caller's
+                # (page-locked) host framebuffer; kernel + resolve + one DMA read-back per frame
+                buf = rt.host_framebuffer(H, W)
+                try:
+                    rt.render(cam, W, H, args.spp, args.depth, strict_fp=bool(args.strict), seed=0, chunk_spp=chunk, out=buf)
+                    t1 = time.perf_counter()
+                    for _ in range(args.readback_steps):
+                        rst = rt.render(cam, W, H, args.spp, args.depth, strict_fp=bool(args.strict), seed=0,
+                                        chunk_spp=chunk, out=buf)["stats"]
+                    rdt = time.perf_counter() - t1
+                    assert np.array_equal(buf, img), "host-pointer entry and device-pointer entry disagree"
+                    out["value_with_readback"] = round(samples * args.readback_steps / rdt / 1e6, 3)
+                    out["readback"] = {"steps": args.readback_steps, "ms_per_step": round(rdt / args.readback_steps * 1e3, 3),
+                                       "kernel_ms": round(float(rst.kernel_ms), 3), "resolve_ms": round(float(rst.resolve_ms), 3),
+                                       "frame_bytes": int(W * H * 4),
+                                       "into": "page-locked host memory (rt_host_alloc), PCIe-inclusive"}
+                finally:
+                    rt.host_free(buf)
+            if not args.no_cpu:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_width, args.cpu_spp, args.depth, args.cpu_threads)
         print(json.dumps(out), flush=True)
 
     rt.shutdown()

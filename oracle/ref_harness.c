@@ -14,6 +14,8 @@
  *   camera  19 f32 (pos, pixel00, du, dv, disk_u, disk_v, defocus_angle) + 2 u32 (W,H)
  *           (environment REF_CAM_POS="x,y,z" moves the eye point for every command)
  *   mc      RGBA8 image, reference render_tile per 64x64 tile (per-tile LCG seed)
+ *   mcref   as mc, with the reference's own threading shape (Main.c:1002-1054): `threads` slots,
+ *           one OS thread created per tile, slot i % threads joined before it is reused
  *   mcser   RGBA8 image, render_all's loop order on one thread (seed 0)
  *   d0      int32 primary-hit index per pixel (centre ray from camera.pos)
  *   d1      constant-u render (fast_rand() == 16384): per pixel 3 f32 linear colour,
@@ -37,6 +39,12 @@ static void *tile_worker(void *arg)
         if (i >= g_ntiles) break;
         render_tile(&g_tiles[i]);
     }
+    return NULL;
+}
+
+static void *one_tile(void *arg)
+{
+    render_tile((tile_data_t *)arg);
     return NULL;
 }
 
@@ -116,10 +124,32 @@ int main(int argc, char **argv)
         fwrite(&gc.camera.defocus_angle, 4, 1, f);
         fwrite(&W, 4, 1, f);
         fwrite(&H, 4, 1, f);
-    } else if (!strcmp(cmd, "mc") || !strcmp(cmd, "mcser")) {
+    } else if (!strcmp(cmd, "mc") || !strcmp(cmd, "mcser") || !strcmp(cmd, "mcref")) {
         gc.draw_buffer.width = W; gc.draw_buffer.height = H;
         gc.draw_buffer.pixels = calloc((size_t)W * H, sizeof(color4_t));
-        if (!strcmp(cmd, "mc")) {
+        if (!strcmp(cmd, "mcref")) {
+            /* the dispatch of render_all_parallel (Main.c:1002-1054) around the reference's render_tile */
+            const u32 ts = 64;
+            u32 tx_n = CEIL_DIV(W, ts), ty_n = CEIL_DIV(H, ts);
+            if (nthreads < 1) nthreads = 1;
+            g_tiles = calloc((size_t)tx_n * ty_n, sizeof(tile_data_t));
+            pthread_t *slot = calloc((size_t)nthreads, sizeof(pthread_t));
+            int created = 0;
+            for (u32 ty = 0; ty < ty_n; ty++)
+                for (u32 tx = 0; tx < tx_n; tx++) {
+                    u32 sx = tx * ts, sy = ty * ts;
+                    int i = created;
+                    g_tiles[i] = (tile_data_t){
+                        .start_x = sx, .end_x = (sx + ts > W) ? W : sx + ts,
+                        .start_y = sy, .end_y = (sy + ts > H) ? H : sy + ts,
+                        .width = W, .height = H };
+                    if (i >= nthreads) pthread_join(slot[i % nthreads], NULL);
+                    if (pthread_create(&slot[i % nthreads], NULL, one_tile, &g_tiles[i]) != 0) { perror("pthread_create"); return 1; }
+                    created++;
+                }
+            int live = created < nthreads ? created : nthreads;
+            for (int i = 0; i < live; i++) pthread_join(slot[(created - live + i) % nthreads], NULL);
+        } else if (!strcmp(cmd, "mc")) {
             const u32 ts = 64;   /* Main.c:1003 */
             u32 tx_n = CEIL_DIV(W, ts), ty_n = CEIL_DIV(H, ts);
             g_tiles = calloc((size_t)tx_n * ty_n, sizeof(tile_data_t));

@@ -414,6 +414,15 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
                     "rays whose nearest hit differs from the all-spheres exact test: %llu\n",
                     c[5], (double)c[2] / c[5], (double)c[7] / c[5], (double)c[3] / c[5], (double)c[4] / c[5],
                     (double)(c[6] & ((1ULL << 40) - 1)) / c[5], c[6] >> 40, c[1], c[8]);
+#ifdef RT_DIAG_STAMPS
+            {
+                const double tot = (double)(c[9] + c[10] + c[11] + c[12] + c[13] + c[14] + c[15]);
+                fprintf(stderr, "diag: wave-cycles per phase (share of the main loop): unit hand-out %.2f %%, new sample %.2f %%, "
+                        "pair scan + appends %.2f %%, drain %.2f %%, big spheres %.2f %%, shade %.2f %%, shared-ray search %.2f %%; "
+                        "%.0f cycles per wave scan\n", 100.0 * c[9] / tot, 100.0 * c[10] / tot, 100.0 * c[11] / tot, 100.0 * c[12] / tot,
+                        100.0 * c[13] / tot, 100.0 * c[14] / tot, 100.0 * c[15] / tot, tot / (double)c[5]);
+            }
+#endif
 #endif
             st.sphere_tests = c[1] * (uint64_t)g.n;
             float ms = 0.0f;

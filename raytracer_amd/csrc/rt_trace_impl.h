@@ -242,10 +242,20 @@ __device__ __forceinline__ void exact_test(const float4 *s_geom, int i, Probe &q
 }
 
 #ifdef RT_DIAG
-// Diagnostic build only: where the non-scan instructions go.
-struct Diag { uint32_t branches, passes, drain_iters, drain_lanes, scans, scan_lanes, shared_rays, lost_hits; };
+// Diagnostic builds only: where the non-scan instructions go.  RT_DIAG_BRUTE adds the exact test over
+// all spheres per ray (lost_hits); RT_DIAG_STAMPS adds shader-clock stamps at the phase boundaries of
+// the main loop (wave-cycles per phase, summed over waves; a stamp drains the scalar-memory queue).
+struct Diag {
+    uint32_t branches, passes, drain_iters, drain_lanes, scans, scan_lanes, shared_rays, lost_hits;
+    unsigned long long t_handout, t_regen, t_hit, t_drain, t_big, t_shade, t_shared;
+};
 #define RT_DIAG_ARG , Diag &dg
 #define RT_DIAG_PASS , dg
+#ifdef RT_DIAG_STAMPS
+#define RT_STAMP() __builtin_amdgcn_s_memtime()
+#else
+#define RT_STAMP() 0ULL
+#endif
 #else
 #define RT_DIAG_ARG
 #define RT_DIAG_PASS
@@ -261,12 +271,18 @@ static_assert(kGeomPad == 2 * kPairBatch, "the sphere list is padded to whole ba
 // j-th sphere index the lane queued (slot-major: a lane's LDS bank does not depend on j).
 __device__ __forceinline__ void drain(const float4 *s_geom, const uint32_t *queue, int cnt, int lane, Probe &q RT_DIAG_ARG)
 {
+#ifdef RT_DIAG
+    const unsigned long long t0 = RT_STAMP();
+#endif
     for (int j = 0; __ballot(j < cnt) != 0ULL; j++) {
 #ifdef RT_DIAG
         dg.drain_iters++; dg.drain_lanes += (uint32_t)__popcll(__ballot(j < cnt));
 #endif
         if (j < cnt) exact_test(s_geom, (int)queue[j * 64 + lane], q);
     }
+#ifdef RT_DIAG
+    dg.t_drain += RT_STAMP() - t0;
+#endif
 }
 
 // hit() (Main.c:688-713) as filter + exact test.
@@ -282,7 +298,13 @@ __device__ __forceinline__ void drain(const float4 *s_geom, const uint32_t *queu
 __device__ __forceinline__ void scan_spheres(const TraceParams &p, const float4 *s_geom, uint32_t *queue, int lane,
                                              float ux, float uy, float uz, float slack_scale, Probe &q RT_DIAG_ARG)
 {
+#ifdef RT_DIAG
+    const unsigned long long tb0 = RT_STAMP();
+#endif
     for (int b = 0; b < p.nbig; b++) exact_test(s_geom, p.big[b], q);
+#ifdef RT_DIAG
+    dg.t_big += RT_STAMP() - tb0;
+#endif
 
     const float ox = q.ox, oy = q.oy, oz = q.oz;
     const float oo = fmaf(oz, oz, fmaf(oy, oy, ox * ox));
@@ -478,7 +500,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(cons
     pool_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_next);       // wave-uniform by construction
     pool_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_end);
 #ifdef RT_DIAG
-    Diag dg = {0, 0, 0, 0, 0, 0, 0, 0};
+    Diag dg = {0, 0, 0, 0, 0, 0, 0, 0, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
 #endif
 
     for (;;) {
@@ -488,6 +510,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(cons
         // per pool, not once per hand-out (thousands of waves on one address saturate the atomic
         // unit).  The first pool of every wave is static (units wave*64 ...), so a launch does
         // not open with one atomic per wave either; the counter hands out what lies beyond.
+#ifdef RT_DIAG
+        const unsigned long long ts0 = RT_STAMP();
+#endif
         unsigned long long want = __ballot(active && need_unit);
         while (want != 0ULL) {
             if (pool_next == pool_end) {
@@ -531,6 +556,10 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(cons
             want = __ballot(active && need_unit);
         }
         if (__ballot(active) == 0ULL) break;
+#ifdef RT_DIAG
+        const unsigned long long ts1 = RT_STAMP();
+        dg.t_handout += ts1 - ts0;
+#endif
 
         // ---- start a new sample where the previous path ended ------------------------
         if (active && need_sample) {
@@ -540,6 +569,10 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(cons
             L.bounce = 0;
             need_sample = false;
         }
+#ifdef RT_DIAG
+        const unsigned long long ts2 = RT_STAMP();
+        dg.t_regen += ts2 - ts1;
+#endif
         // ---- hit(): nearest sphere along the ray, Main.c:688-713 -----------------------
         Probe q;
         q.ox = L.o.x; q.oy = L.o.y; q.oz = L.o.z;
@@ -574,6 +607,10 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(cons
         if (L.zero_dir) q.hit = -1;
 #endif
 #ifdef RT_DIAG
+        const unsigned long long ts3 = RT_STAMP();
+        if (__popcll(__ballot(active)) <= p.coop_max) dg.t_shared += ts3 - ts2; else dg.t_hit += ts3 - ts2;
+#endif
+#ifdef RT_DIAG_BRUTE
         {
             // Diagnostic build: the exact test over ALL spheres, in index order, must agree with what
             // the filter, the queues and the drain (or the shared-ray search) found for this ray.
@@ -696,6 +733,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(cons
                 }
             }
         }
+#ifdef RT_DIAG
+        dg.t_shade += RT_STAMP() - ts3;
+#endif
     }
 
     // ---- statistics: rays cast ---------------------------------------------------------
@@ -716,6 +756,17 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(cons
         for (int off = 32; off > 0; off >>= 1) lost += __shfl_down(lost, off);
         if (__lane_id() == 0 && lost != 0ULL) atomicAdd(&p.counters[8], lost);
     }
+#ifdef RT_DIAG_STAMPS
+    if (__lane_id() == 0) {
+        atomicAdd(&p.counters[9], dg.t_handout);
+        atomicAdd(&p.counters[10], dg.t_regen);
+        atomicAdd(&p.counters[11], dg.t_hit - dg.t_drain - dg.t_big);      // the pair loop with its appends
+        atomicAdd(&p.counters[12], dg.t_drain);
+        atomicAdd(&p.counters[13], dg.t_big);
+        atomicAdd(&p.counters[14], dg.t_shade);
+        atomicAdd(&p.counters[15], dg.t_shared);
+    }
+#endif
 #endif
 }
 

@@ -40,6 +40,10 @@ def psnr(a, b):
 @pytest.fixture(scope="session")
 def rt():
     """The product library, initialised on GPU 0.  No fallback: raises if unavailable."""
+    try:
+        import torch  # noqa: F401  (PyTorch's bundled HIP runtime must load before the system one the library links)
+    except ImportError:
+        pass
     import raytracer_amd as rt_
     rt_.init(0)
     yield rt_

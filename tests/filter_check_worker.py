@@ -31,10 +31,11 @@ def main():
         else:
             sph = ss.random_scene(kind)
             W, H, spp, depth = 320, 180, 6, 12
-            cam = rt.camera(W, H, ss.view_params(rt, kind, defocus_angle=0.6))
         rt.set_world(sph)
         for strict in (False, True):
             for mode in (rt.MODE_MC, rt.MODE_CONST_U):
+                if kind is not None:
+                    cam = rt.camera(W, H, ss.view_params(rt, kind, defocus_angle=0.6 if mode == rt.MODE_MC else 0.0))
                 r = rt.render(cam, W, H, spp if mode == rt.MODE_MC else 1, depth, mode=mode, strict_fp=strict,
                               seed=7, chunk_spp=2, want_hit=True)
                 c = (C.c_ulonglong * 16)()

@@ -260,7 +260,8 @@ def test_strict_build_matches_checker_on_filter_stress_scenes(rt, kind):
         assert np.array_equal(bits(r["accum"]), bits(c["accum"]))
         assert np.array_equal(r["rgba"], c["rgba"])
         assert int(r["stats"].rays) == int(c["stats"].rays)
-    assert (r["hit"] >= 0).mean() > 0.05                     # the view does see the scene
+        if mode == rt.MODE_CONST_U:
+            assert (r["hit"] >= 0).mean() > 0.05             # the view does see the scene
 
 
 def test_filter_and_drain_equal_brute_force(rt):
@@ -284,7 +285,7 @@ def test_filter_and_drain_equal_brute_force(rt):
         print(row)
         assert row["rays"] > 0 and row["lost_hits"] == 0, row
     assert sum(r["wave_scans"] for r in rows) > 0 and sum(r["queued"] for r in rows) > 0
-    assert all(r["seen"] > 0.05 for r in rows)
+    assert all(r["seen"] > 0.05 for r in rows if r["mode"] == 1)    # the undefocused views do see their scenes
 
 
 @pytest.mark.parametrize("kind", ["wide", "tiny", "nested"])

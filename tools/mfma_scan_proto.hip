@@ -1,0 +1,404 @@
+// Prototype of the conservative sphere filter on the matrix cores (bf16 x 3 split, f32 accumulate)
+// against the packed-FP32 vector scan the kernel uses now.  Standalone: hipcc --offload-arch=gfx950 -O3.
+//   mfma_scan_proto <scene.bin> [reps]
+// Checks, per ray, that the matrix filter's candidate set contains every sphere whose exact
+// discriminant (double precision, host) is >= 0, compares its size with the vector filter's, and times both.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(4))) f8 const_f8;
+
+struct Ray { float ox, oy, oz, dx, dy, dz; };     // d is unit length
+
+struct Params {
+    const Ray *rays;          // [nbatch][64 * waves_total] laid out batch-major
+    int nbatch;
+    const float *pairs;       // vector scan: [n_pad/2][8]
+    const uint4 *aimg;        // matrix scan: [ntiles][2][64] packed bf16 fragments
+    int n_pad, ntiles;
+    float c_near;
+    float slack_scale;
+    unsigned *out_count;      // [nrays] candidates per ray
+    unsigned *out_sum;        // [nrays] sum of candidate indices per ray
+    unsigned long long *out_total;
+};
+
+constexpr int kSlots = 24;
+
+// ---- the vector scan (as in the library's kernel) ---------------------------------------------
+template <bool CHECKED>
+__global__ __launch_bounds__(256, 7) void scan_vector(const Params p)
+{
+    extern __shared__ uint32_t lds[];
+    const int lane = (int)__lane_id();
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int nw = gridDim.x * (blockDim.x >> 6);
+    uint32_t *queue = lds + (threadIdx.x >> 6) * (kSlots * 64);
+    unsigned long long total = 0;
+    for (int b = 0; b < p.nbatch; b++) {
+        const size_t rid = ((size_t)b * nw + wave) * 64 + lane;
+        const Ray r = p.rays[rid];
+        const float oo = fmaf(r.oz, r.oz, fmaf(r.oy, r.oy, r.ox * r.ox));
+        const float reach = __builtin_amdgcn_sqrtf(oo) * 1.0000005f + p.c_near;
+        const float slack = fmaf(reach * reach, p.slack_scale, 1e-30f);
+        const float base = slack - oo;
+        const float ndo = -fmaf(r.dz, r.oz, fmaf(r.dy, r.oy, r.dx * r.ox));
+        const float ox2 = r.ox + r.ox, oy2 = r.oy + r.oy, oz2 = r.oz + r.oz;
+        const_f8 *gp = (const_f8 *)p.pairs;
+        const int npairs = p.n_pad >> 1;
+        int cnt = 0;
+        unsigned sum = 0, count = 0;
+        f8 ahead = gp[0];
+        for (int k0 = 0; k0 < npairs; k0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const f8 s = ahead;
+                ahead = gp[k0 + u + 1];
+                const f2 cx = {s[0], s[1]}, cy = {s[2], s[3]}, cz = {s[4], s[5]};
+                f2 h = __builtin_elementwise_fma(cx, (f2)r.dx, (f2)ndo);
+                h = __builtin_elementwise_fma(cy, (f2)r.dy, h);
+                h = __builtin_elementwise_fma(cz, (f2)r.dz, h);
+                f2 m = __builtin_elementwise_fma(cx, (f2)ox2, (f2)base);
+                m = __builtin_elementwise_fma(cy, (f2)oy2, m);
+                m = __builtin_elementwise_fma(cz, (f2)oz2, m);
+                const f2 e = __builtin_elementwise_fma(h, h, m);
+                const bool px = e.x >= s[6], py = e.y >= s[7];
+                if (__ballot(px || py) != 0ULL) {
+                    if (px) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u)); cnt++; }
+                    if (py) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u) + 1); cnt++; }
+                }
+            }
+            if (__ballot(cnt > kSlots - 8) != 0ULL) {
+                for (int j = 0; j < cnt; j++) { sum += queue[j * 64 + lane]; count++; }
+                cnt = 0;
+            }
+        }
+        for (int j = 0; j < cnt; j++) { sum += queue[j * 64 + lane]; count++; }
+        total += count;
+        if (CHECKED) { p.out_count[rid] = count; p.out_sum[rid] = sum; }
+    }
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off);
+    if (lane == 0) atomicAdd(p.out_total, total);
+}
+
+// ---- the matrix scan ----------------------------------------------------------------------
+// Per sphere: features (cx, cy, cz, 1, k = |C|^2 - r^2); per ray: D1 = d.C - d.O, D2 = 2 O.C - k;
+// e = D1^2 + D2 >= |O|^2 - slack  <=>  discriminant >= -slack.  Every f32 factor is split into three
+// bf16 pieces x = x1 + x2 + x3 (8 significant bits each) and the six piece products of weight
+// >= 2^-16 are summed by the MFMA in f32: K entries per feature (c1 p1, c1 p2, c2 p1, c1 p3, c3 p1, c2 p2).
+__device__ __forceinline__ uint32_t top16(float x) { return __float_as_uint(x) & 0xffff0000u; }
+
+struct Split { uint32_t p1, p2, p3; };           // bf16 pieces in the upper halves
+
+__device__ __forceinline__ Split split3(float x)
+{
+    Split s;
+    s.p1 = top16(x);
+    const float r1 = x - __uint_as_float(s.p1);
+    s.p2 = top16(r1);
+    const float r2 = r1 - __uint_as_float(s.p2);
+    s.p3 = top16(r2);
+    return s;
+}
+
+__device__ __forceinline__ uint32_t pack(uint32_t lo_piece, uint32_t hi_piece) { return (lo_piece >> 16) | hi_piece; }
+
+__device__ __forceinline__ bf16x8 frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    uint4 v = make_uint4(a, b, c, d);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool CHECKED>
+__global__ __launch_bounds__(512, 2) void scan_matrix(const Params p)
+{
+    extern __shared__ uint32_t lds[];
+    const int lane = (int)__lane_id();
+    const int wib = threadIdx.x >> 6;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + wib;
+    const int nw = gridDim.x * (blockDim.x >> 6);
+    uint4 *s_a = reinterpret_cast<uint4 *>(lds);                               // [ntiles][2][64]
+    for (int i = threadIdx.x; i < p.ntiles * 128; i += blockDim.x) s_a[i] = p.aimg[i];
+    uint32_t *queue = lds + p.ntiles * 128 * 4 + wib * (2 * kSlots * 64);        // [2][kSlots][64]
+    __syncthreads();
+    const int h = lane >> 5;
+    unsigned long long total = 0;
+    for (int b = 0; b < p.nbatch; b++) {
+        const size_t rid = ((size_t)b * nw + wave) * 64 + lane;
+        const Ray r = p.rays[rid];
+        const float oo = fmaf(r.oz, r.oz, fmaf(r.oy, r.oy, r.ox * r.ox));
+        const float reach = __builtin_amdgcn_sqrtf(oo) * 1.0000005f + p.c_near;
+        const float slack = fmaf(reach * reach, p.slack_scale, 1e-30f);
+        const float thr_own = oo - slack;
+        const float ndo = -fmaf(r.dz, r.oz, fmaf(r.dy, r.oy, r.dx * r.ox));
+        // own K entries, packed two bf16 per register: groups (s, h) = (0,0) (0,1) (1,0); (1,1) is zero
+        const Split dx = split3(r.dx), dy = split3(r.dy), dz = split3(r.dz), nn = split3(ndo);
+        const Split ox = split3(r.ox + r.ox), oy = split3(r.oy + r.oy), oz = split3(r.oz + r.oz);
+        const uint32_t m1 = 0xbf800000u;            // -1.0f: its upper half is bf16 -1
+        uint32_t g1[3][4], g2[3][4];
+        g1[0][0] = pack(dx.p1, dx.p2); g1[0][1] = pack(dx.p1, dx.p3); g1[0][2] = g1[0][0]; g1[0][3] = pack(dy.p1, dy.p2);
+        g1[1][0] = pack(dy.p1, dy.p3); g1[1][1] = g1[0][3]; g1[1][2] = pack(dz.p1, dz.p2); g1[1][3] = pack(dz.p1, dz.p3);
+        g1[2][0] = g1[1][2]; g1[2][1] = pack(nn.p1, nn.p2); g1[2][2] = pack(nn.p3, 0u); g1[2][3] = 0u;
+        g2[0][0] = pack(ox.p1, ox.p2); g2[0][1] = pack(ox.p1, ox.p3); g2[0][2] = g2[0][0]; g2[0][3] = pack(oy.p1, oy.p2);
+        g2[1][0] = pack(oy.p1, oy.p3); g2[1][1] = g2[0][3]; g2[1][2] = pack(oz.p1, oz.p2); g2[1][3] = pack(oz.p1, oz.p3);
+        g2[2][0] = g2[1][2]; g2[2][1] = 0u; g2[2][2] = pack(0u, m1); g2[2][3] = pack(m1, m1);
+        // fragments of the two ray halves: half H holds rays 32H .. 32H+31 in its columns; lanes 0-31
+        // supply K entries 0-7 of an instruction, lanes 32-63 entries 8-15, of the COLUMN's ray
+        uint32_t B1[2][2][4], B2[2][2][4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            auto s0 = __builtin_amdgcn_permlane32_swap(g1[0][v], g1[1][v], false, false);
+            B1[0][0][v] = s0[0]; B1[1][0][v] = s0[1];
+            auto s1 = __builtin_amdgcn_permlane32_swap(g1[2][v], 0u, false, false);
+            B1[0][1][v] = s1[0]; B1[1][1][v] = s1[1];
+            auto t0 = __builtin_amdgcn_permlane32_swap(g2[0][v], g2[1][v], false, false);
+            B2[0][0][v] = t0[0]; B2[1][0][v] = t0[1];
+            auto t1 = __builtin_amdgcn_permlane32_swap(g2[2][v], 0u, false, false);
+            B2[0][1][v] = t1[0]; B2[1][1][v] = t1[1];
+        }
+        float thr[2];
+        {
+            auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(thr_own), __float_as_uint(thr_own), false, false);
+            thr[0] = __uint_as_float(s[0]);      // lanes < 32: own; lanes >= 32: thr of lane - 32   (column ray of half 0)
+            thr[1] = __uint_as_float(s[1]);      // lanes < 32: thr of lane + 32; lanes >= 32: own    (column ray of half 1)
+        }
+        int cnt[2] = {0, 0};
+        unsigned sum = 0, count = 0;
+        const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = 0; t < p.ntiles; t++) {
+            const uint4 a0u = s_a[(t * 2 + 0) * 64 + lane], a1u = s_a[(t * 2 + 1) * 64 + lane];
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, a0u), a1 = __builtin_bit_cast(bf16x8, a1u);
+#pragma unroll
+            for (int H = 0; H < 2; H++) {
+                f32x16 d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, frag(B1[H][0][0], B1[H][0][1], B1[H][0][2], B1[H][0][3]), zero, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, frag(B1[H][1][0], B1[H][1][1], B1[H][1][2], B1[H][1][3]), d1, 0, 0, 0);
+                f32x16 d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, frag(B2[H][0][0], B2[H][0][1], B2[H][0][2], B2[H][0][3]), zero, 0, 0, 0);
+                d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, frag(B2[H][1][0], B2[H][1][1], B2[H][1][2], B2[H][1][3]), d2, 0, 0, 0);
+                const float th = thr[H];
+                uint32_t *q = queue + H * (kSlots * 64);
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    const float e0 = fmaf(d1[i], d1[i], d2[i]), e1 = fmaf(d1[i + 1], d1[i + 1], d2[i + 1]);
+                    const bool p0 = e0 >= th, p1 = e1 >= th;
+                    if (__ballot(p0 || p1) != 0ULL) {
+                        const int row0 = (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (p0) { q[cnt[H] * 64 + lane] = (uint32_t)(t * 32 + row0); cnt[H]++; }
+                        if (p1) { q[cnt[H] * 64 + lane] = (uint32_t)(t * 32 + row0 + 1); cnt[H]++; }
+                    }
+                }
+            }
+            if (__ballot(cnt[0] > kSlots - 16 || cnt[1] > kSlots - 16) != 0ULL) {
+                // drain (prototype: tally only): a lane's own ray collects from its queue h and its partner's queue h
+                auto c = __builtin_amdgcn_permlane32_swap((unsigned)cnt[0], (unsigned)cnt[1], false, false);
+                const int ca = h ? (int)c[1] : (int)c[0], cb = h ? (int)c[0] : (int)c[1];
+                const uint32_t *qa = queue + h * (kSlots * 64);
+                for (int j = 0; j < ca; j++) { sum += qa[j * 64 + lane]; count++; }
+                for (int j = 0; j < cb; j++) { sum += qa[j * 64 + (lane ^ 32)]; count++; }
+                cnt[0] = 0; cnt[1] = 0;
+            }
+        }
+        {
+            auto c = __builtin_amdgcn_permlane32_swap((unsigned)cnt[0], (unsigned)cnt[1], false, false);
+            const int ca = h ? (int)c[1] : (int)c[0], cb = h ? (int)c[0] : (int)c[1];
+            const uint32_t *qa = queue + h * (kSlots * 64);
+            for (int j = 0; j < ca; j++) { sum += qa[j * 64 + lane]; count++; }
+            for (int j = 0; j < cb; j++) { sum += qa[j * 64 + (lane ^ 32)]; count++; }
+        }
+        total += count;
+        if (CHECKED) { p.out_count[rid] = count; p.out_sum[rid] = sum; }
+    }
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off);
+    if (lane == 0) atomicAdd(p.out_total, total);
+}
+
+// ---- host -----------------------------------------------------------------------------------
+struct Sphere { float c[3], r; int mat; float alb[3], fuzz, ior; };
+
+static uint16_t bf16_trunc(float x) { uint32_t u; memcpy(&u, &x, 4); return (uint16_t)(u >> 16); }
+static float bf16_val(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+static void split3h(float x, uint16_t out[3])
+{
+    out[0] = bf16_trunc(x); float r1 = x - bf16_val(out[0]);
+    out[1] = bf16_trunc(r1); float r2 = r1 - bf16_val(out[1]);
+    out[2] = bf16_trunc(r2);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: %s scene.bin [nbatch]\n", argv[0]); return 2; }
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) { perror(argv[1]); return 1; }
+    std::vector<Sphere> sph;
+    Sphere s;
+    while (fread(&s, sizeof s, 1, f) == 1) sph.push_back(s);
+    fclose(f);
+    const int n = (int)sph.size();
+    const int nbatch = argc > 2 ? atoi(argv[2]) : 8;
+    printf("%d spheres\n", n);
+
+    // big spheres (excluded from the filter): extent > 4 x median
+    std::vector<double> ext(n);
+    for (int i = 0; i < n; i++) ext[i] = sqrt((double)sph[i].c[0] * sph[i].c[0] + (double)sph[i].c[1] * sph[i].c[1] + (double)sph[i].c[2] * sph[i].c[2]) + sph[i].r;
+    std::vector<double> so = ext; std::sort(so.begin(), so.end());
+    const double big_from = 4.0 * so[n / 2];
+    std::vector<char> big(n, 0);
+    double c_near = 0;
+    for (int i = 0; i < n; i++) { big[i] = ext[i] > big_from; if (!big[i]) c_near = std::max(c_near, ext[i] - sph[i].r); }
+
+    const int n_pad = (n + 7) / 8 * 8;
+    std::vector<float> pairs((size_t)n_pad * 4 + 8, 0.0f);
+    for (int i = 0; i < n_pad; i++) {
+        float *q = &pairs[(size_t)(i / 2) * 8 + (i & 1)];
+        if (i < n && !big[i]) {
+            q[0] = sph[i].c[0]; q[2] = sph[i].c[1]; q[4] = sph[i].c[2];
+            q[6] = (float)((double)sph[i].c[0] * sph[i].c[0] + (double)sph[i].c[1] * sph[i].c[1] + (double)sph[i].c[2] * sph[i].c[2] - (double)sph[i].r * sph[i].r);
+        } else { q[6] = INFINITY; }
+    }
+    // matrix image: [tile][s][lane] 8 bf16: lane l: sphere tile*32 + (l & 31), K entries 16 s + 8 (l >> 5) + j
+    const int ntiles = (n + 31) / 32;
+    std::vector<uint16_t> aimg((size_t)ntiles * 2 * 64 * 8, 0);
+    for (int t = 0; t < ntiles; t++)
+        for (int row = 0; row < 32; row++) {
+            const int i = t * 32 + row;
+            uint16_t ent[32];
+            memset(ent, 0, sizeof ent);
+            if (i < n && !big[i]) {
+                for (int c = 0; c < 3; c++) {
+                    uint16_t p[3];
+                    split3h(sph[i].c[c], p);
+                    const uint16_t six[6] = {p[0], p[0], p[1], p[0], p[2], p[1]};
+                    for (int k = 0; k < 6; k++) ent[6 * c + k] = six[k];
+                }
+                ent[18] = ent[19] = ent[20] = bf16_trunc(1.0f);
+                const float k = (float)((double)sph[i].c[0] * sph[i].c[0] + (double)sph[i].c[1] * sph[i].c[1] + (double)sph[i].c[2] * sph[i].c[2] - (double)sph[i].r * sph[i].r);
+                uint16_t kp[3];
+                split3h(k, kp);
+                ent[21] = kp[0]; ent[22] = kp[1]; ent[23] = kp[2];
+            } else {
+                ent[21] = bf16_trunc(3.0e38f);       // never passes: D2 = -3e38
+            }
+            for (int s2 = 0; s2 < 2; s2++)
+                for (int hh = 0; hh < 2; hh++)
+                    for (int j = 0; j < 8; j++)
+                        aimg[(((size_t)t * 2 + s2) * 64 + hh * 32 + row) * 8 + j] = ent[16 * s2 + 8 * hh + j];
+        }
+
+    // rays: half camera rays, half rays leaving small spheres
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    const int waves_v = cus * 28, waves_m = cus * 8;
+    const int nw = std::max(waves_v, waves_m);
+    const size_t nrays = (size_t)nbatch * nw * 64;
+    std::vector<Ray> rays(nrays);
+    std::mt19937 rng(12345);
+    std::uniform_real_distribution<float> U(0.0f, 1.0f);
+    for (size_t i = 0; i < nrays; i++) {
+        Ray r;
+        float d[3];
+        if (rng() & 1) {
+            r.ox = 13.0f + 0.3f * (U(rng) - 0.5f); r.oy = 2.0f + 0.3f * (U(rng) - 0.5f); r.oz = 3.0f + 0.3f * (U(rng) - 0.5f);
+            float tx = -11.0f + 22.0f * U(rng) * 0.6f, ty = -0.5f + 3.0f * U(rng), tz = -6.0f + 12.0f * U(rng);
+            d[0] = tx - r.ox; d[1] = ty - r.oy; d[2] = tz - r.oz;
+        } else {
+            const Sphere &sp = sph[1 + rng() % (n - 1)];
+            float z = 1 - 2 * U(rng), ph = 6.2831853f * U(rng), rad = sqrtf(std::max(0.0f, 1 - z * z));
+            float nx = rad * cosf(ph), ny = rad * sinf(ph), nz = z;
+            r.ox = sp.c[0] + sp.r * nx; r.oy = sp.c[1] + sp.r * ny; r.oz = sp.c[2] + sp.r * nz;
+            float z2 = 1 - 2 * U(rng), ph2 = 6.2831853f * U(rng), rad2 = sqrtf(std::max(0.0f, 1 - z2 * z2));
+            d[0] = nx + rad2 * cosf(ph2); d[1] = ny + rad2 * sinf(ph2); d[2] = nz + z2;
+        }
+        float l = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        if (!(l > 1e-6f)) { d[0] = 0; d[1] = 1; d[2] = 0; l = 1; }
+        r.dx = d[0] / l; r.dy = d[1] / l; r.dz = d[2] / l;
+        rays[i] = r;
+    }
+
+    Params p;
+    memset(&p, 0, sizeof p);
+    Ray *d_rays; float *d_pairs; uint4 *d_aimg; unsigned *d_cnt, *d_sum; unsigned long long *d_total;
+    CHECK(hipMalloc(&d_rays, nrays * sizeof(Ray)));
+    CHECK(hipMalloc(&d_pairs, pairs.size() * 4));
+    CHECK(hipMalloc(&d_aimg, aimg.size() * 2));
+    CHECK(hipMalloc(&d_cnt, nrays * 4));
+    CHECK(hipMalloc(&d_sum, nrays * 4));
+    CHECK(hipMalloc(&d_total, 8));
+    CHECK(hipMemcpy(d_rays, rays.data(), nrays * sizeof(Ray), hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_pairs, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_aimg, aimg.data(), aimg.size() * 2, hipMemcpyHostToDevice));
+    p.rays = d_rays; p.nbatch = nbatch; p.pairs = d_pairs; p.aimg = d_aimg; p.n_pad = n_pad; p.ntiles = ntiles;
+    p.c_near = (float)c_near; p.out_count = d_cnt; p.out_sum = d_sum; p.out_total = d_total;
+
+    const size_t lds_v = 4 * kSlots * 64 * 4;
+    const size_t lds_m = (size_t)ntiles * 128 * 16 + 8 * 2 * kSlots * 64 * 4;
+    CHECK(hipFuncSetAttribute((const void *)scan_matrix<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+    CHECK(hipFuncSetAttribute((const void *)scan_matrix<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+
+    // ---- check: candidate sets
+    std::vector<unsigned> cv(nrays), sv(nrays), cm(nrays), sm(nrays);
+    const size_t ncheck = (size_t)waves_m * 64;           // first batch of the matrix kernel's wave count
+    for (int which = 0; which < 2; which++) {
+        CHECK(hipMemset(d_cnt, 0xff, nrays * 4));
+        CHECK(hipMemset(d_total, 0, 8));
+        Params q = p; q.nbatch = 1;
+        if (which == 0) { q.slack_scale = 1.9073486e-6f; hipLaunchKernelGGL(scan_vector<true>, dim3(waves_m / 4), dim3(256), lds_v, 0, q); }
+        else { q.slack_scale = 3.8146973e-6f; hipLaunchKernelGGL(scan_matrix<true>, dim3(waves_m / 8), dim3(512), lds_m, 0, q); }
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(which ? cm.data() : cv.data(), d_cnt, ncheck * 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(which ? sm.data() : sv.data(), d_sum, ncheck * 4, hipMemcpyDeviceToHost));
+    }
+    size_t exact_total = 0, vec_total = 0, mat_total = 0, mat_missing = 0, vec_missing = 0;
+    for (size_t i = 0; i < ncheck; i++) {
+        const Ray &r = rays[i];
+        unsigned ec = 0, es = 0;
+        for (int k = 0; k < n; k++) {
+            if (big[k]) continue;
+            double ocx = (double)sph[k].c[0] - r.ox, ocy = (double)sph[k].c[1] - r.oy, ocz = (double)sph[k].c[2] - r.oz;
+            double hh = r.dx * ocx + r.dy * ocy + r.dz * ocz;
+            double disc = hh * hh - (ocx * ocx + ocy * ocy + ocz * ocz - (double)sph[k].r * sph[k].r);
+            if (disc >= 0) { ec++; es += k; }
+        }
+        exact_total += ec; vec_total += cv[i]; mat_total += cm[i];
+        // a superset with equal size and equal index sum is the same set; a smaller set lost a sphere
+        if (cm[i] < ec || (cm[i] == ec && sm[i] != es)) mat_missing++;
+        if (cv[i] < ec || (cv[i] == ec && sv[i] != es)) vec_missing++;
+    }
+    printf("check over %zu rays: exact candidates %.3f per ray; vector filter %.3f (rays with a lost sphere: %zu); matrix filter %.3f (rays with a lost sphere: %zu)\n",
+           ncheck, (double)exact_total / ncheck, (double)vec_total / ncheck, vec_missing, (double)mat_total / ncheck, mat_missing);
+
+    // ---- timing
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int which = 0; which < 2; which++) {
+        Params q = p;
+        q.slack_scale = which ? 3.8146973e-6f : 1.9073486e-6f;
+        const int waves = which ? waves_m : waves_v;
+        for (int rep = 0; rep < 3; rep++) {
+            CHECK(hipEventRecord(e0));
+            if (which == 0) hipLaunchKernelGGL(scan_vector<false>, dim3(waves / 4), dim3(256), lds_v, 0, q);
+            else hipLaunchKernelGGL(scan_matrix<false>, dim3(waves / 8), dim3(512), lds_m, 0, q);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipDeviceSynchronize());
+            float ms = 0;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            const double tests = (double)nbatch * waves * 64 * n;
+            printf("%s scan: %d waves x %d batches: %.3f ms, %.2f G tests/s, algorithmic %.1f TFLOP/s = %.3f of the vector peak\n",
+                   which ? "matrix" : "vector", waves, nbatch, ms, tests / ms / 1e6, 18.0 * tests / ms / 1e9, 18.0 * tests / ms / 1e9 / 157.3);
+        }
+    }
+    return 0;
+}
