@@ -175,6 +175,22 @@ int rt_render(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t heig
 int rt_render_device(const rt_camera *cam, uint8_t *rgba_dev, uint32_t width, uint32_t height,
                      int spp, int max_depth, const rt_opts *opts);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory around the
+ * call (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the same
+ * as rt_render_device, but the per-chunk partial sums and the work/ray counters live in a fixed
+ * array of RT_NOALLOC_SCRATCH_BYTES in the library's code object (one copy per GPU, held until the
+ * process ends) instead of buffers the library grows on demand; the call runs no hipMalloc, hipFree
+ * or other allocating routine.  Call rt_set_world first (it loads the kernels and looks up their
+ * launch geometry).  Limits: owned pixels x ceil(spp / chunk_spp) x 16 bytes must fit
+ * RT_NOALLOC_SCRATCH_BYTES - 256 (1920x1080 in up to two chunks; chunk_spp = 0 is always one
+ * chunk), else RT_ERR_ARG with the sizes in rt_last_error(); opts->rows is not supported
+ * (part_index / part_count are).  Results equal rt_render_device's for the same arguments, bit for
+ * bit.  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU race;
+ * the library's other entry points do not touch the array. */
+#define RT_NOALLOC_SCRATCH_BYTES (64u << 20)
+int rt_render_device_noalloc(const rt_camera *cam, uint8_t *rgba_dev, uint32_t width, uint32_t height,
+                             int spp, int max_depth, const rt_opts *opts);
+
 /* Progressive display (no counterpart in the reference, which re-renders identical frames,
  * Main.c:1440-1443): frame `frame_index` adds `spp` new samples per pixel (sample indices
  * sample_base + frame_index*spp ...) to a per-pixel sum kept on the device and writes the

@@ -59,7 +59,7 @@ SPHERE_DTYPE = np.dtype([("center", "<f4", 3), ("radius", "<f4"), ("mat_type", "
                          ("albedo", "<f4", 3), ("fuzz", "<f4"), ("ior", "<f4")])
 assert SPHERE_DTYPE.itemsize == 40
 
-EXPORTS = ["rt_init", "rt_init_devices", "rt_set_world", "rt_render", "rt_render_device",
+EXPORTS = ["rt_init", "rt_init_devices", "rt_set_world", "rt_render", "rt_render_device", "rt_render_device_noalloc",
            "rt_render_progressive", "rt_part_rows", "rt_part_row_at", "rt_chunk_for", "rt_camera_setup", "rt_camera_defaults", "rt_height_for",
            "rt_scene_generate", "rt_host_alloc", "rt_host_free", "rt_shutdown", "rt_last_error"]
 
@@ -87,7 +87,7 @@ def lib():
         L.rt_init_devices.argtypes = [C.POINTER(C.c_int), C.c_int]
         L.rt_set_world.restype = C.c_int
         L.rt_set_world.argtypes = [C.c_void_p, C.c_size_t]
-        for f in (L.rt_render, L.rt_render_device):
+        for f in (L.rt_render, L.rt_render_device, L.rt_render_device_noalloc):
             f.restype = C.c_int
             f.argtypes = [C.POINTER(Camera), C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
                           C.POINTER(Opts)]
@@ -246,6 +246,9 @@ def render_progressive(cam, width, height, spp, max_depth, frame_index, mode=MOD
     return dict(rgba=rgba, accum=acc, stats=st)
 
 
+NOALLOC_SCRATCH_BYTES = 64 << 20      # RT_NOALLOC_SCRATCH_BYTES
+
+
 def chunk_for(width, height, spp, chunk_spp=CHUNK_AUTO, progressive=False):
     """rt_chunk_for: the samples per work unit a render of this full image size uses."""
     return int(lib().rt_chunk_for(width, height, spp, chunk_spp, int(bool(progressive))))
@@ -253,13 +256,15 @@ def chunk_for(width, height, spp, chunk_spp=CHUNK_AUTO, progressive=False):
 
 def render_device(cam, rgba_dev_ptr, width, height, spp, max_depth, mode=MODE_MC, strict_fp=False,
                   seed=0, sample_base=0, chunk_spp=0, tile_rows=0, part_index=0, part_count=0,
-                  hit_dev_ptr=None, accum_dev_ptr=None, rows=None):
-    """rt_render_device: outputs are raw device pointers (e.g. torch.Tensor.data_ptr())."""
+                  hit_dev_ptr=None, accum_dev_ptr=None, rows=None, no_alloc=False):
+    """rt_render_device: outputs are raw device pointers (e.g. torch.Tensor.data_ptr()).
+    no_alloc=True calls rt_render_device_noalloc (scratch in the library's static device array)."""
     st = Stats()
     o = _opts(mode, strict_fp, seed, sample_base, chunk_spp, tile_rows, part_index, part_count, rows)
     o.hit_index_out = hit_dev_ptr
     o.accum_out = accum_dev_ptr
     o.stats = C.addressof(st)
-    _check(lib().rt_render_device(C.byref(cam), rgba_dev_ptr, width, height, spp, max_depth, C.byref(o)),
-           "rt_render_device")
+    fn = lib().rt_render_device_noalloc if no_alloc else lib().rt_render_device
+    _check(fn(C.byref(cam), rgba_dev_ptr, width, height, spp, max_depth, C.byref(o)),
+           "rt_render_device_noalloc" if no_alloc else "rt_render_device")
     return st

@@ -28,10 +28,16 @@
 
 using namespace rtmi;
 
+// Scratch of rt_render_device_noalloc: the work/ray counters (first 256 bytes) and the per-chunk
+// partial sums of one call.  Every device the library runs on holds its own copy until the process
+// ends; host code reaches it only through the per-device address looked up in init_ctx().
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+
 namespace {
 
 constexpr int kCounters = 16;                    // 64-bit words: [0] next work unit, [1] rays cast, the rest diagnostics
 constexpr size_t kScratchCountersBytes = 256;
+constexpr size_t kScratchPartialBytes = (size_t)RT_NOALLOC_SCRATCH_BYTES - kScratchCountersBytes;
 constexpr uint32_t kProgBroken = 0xffffffffu;    // prog_frames of a sequence that must restart at frame 0
 
 struct DevBuf {
@@ -62,6 +68,7 @@ struct Ctx {
     double speed = 1.0;          // rows per kernel-millisecond of the last multi-context frame (weight of the next deal)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    unsigned char *scratch_ptr = nullptr;   // this device's copy of `scratch`
     // world
     int n = 0, n_pad = 0;
     int nbig = 0;
@@ -217,6 +224,7 @@ int resolve_chunk(int chunk_opt, uint32_t width, uint32_t height, int spp, bool 
 
 struct Call {
     bool device_ptrs = false;     // outputs are device pointers (compact over the owned rows)
+    bool no_alloc = false;        // partial sums and counters live in the static scratch array; nothing is allocated
     int64_t frame_index = -1;     // >= 0: progressive frame
     int chunk = 0;                // resolved samples per work unit (resolve_chunk)
 };
@@ -252,6 +260,7 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
 
     const bool explicit_rows = o.rows != nullptr;
     if (explicit_rows) {
+        if (call.no_alloc) return fail(RT_ERR_ARG, "rt_render_device_noalloc: opts->rows is not supported; use part_index / part_count");
         if (o.row_count > height) return fail(RT_ERR_ARG, "rt_render: row_count %u exceeds the image height %u", o.row_count, height);
         for (uint32_t k = 0; k < o.row_count; k++)
             if (o.rows[k] >= height || (k > 0 && o.rows[k] <= o.rows[k - 1]))
@@ -263,6 +272,10 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
     const int nchunks = (spp + chunk - 1) / chunk;
     const uint64_t units = (uint64_t)npix * (uint64_t)nchunks;
     if (units >= 0xffffffffULL) return fail(RT_ERR_ARG, "rt_render: %llu work units; raise chunk_spp", (unsigned long long)units);
+    if (call.no_alloc && units * sizeof(float4) > kScratchPartialBytes)
+        return fail(RT_ERR_ARG, "rt_render_device_noalloc: %u owned pixels x %d chunks need %llu bytes of per-chunk sums; "
+                    "the scratch array holds %llu (raise chunk_spp, or 0 for one chunk, or render fewer rows per call)",
+                    npix, nchunks, (unsigned long long)(units * sizeof(float4)), (unsigned long long)kScratchPartialBytes);
 
     uint32_t sample_base = o.sample_base;
     uint32_t frames_after = 0;
@@ -305,7 +318,7 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
         if (o.accum_out) { HIP_TRY(g.accum.reserve((size_t)npix * 12 + 4)); d_accum = (float *)g.accum.p; }
         if (o.hit_index_out) { HIP_TRY(g.hit.reserve((size_t)npix * 4 + 4)); d_hit = (int32_t *)g.hit.p; }
     }
-    unsigned long long *d_counters = (unsigned long long *)g.counters.p;
+    unsigned long long *d_counters = call.no_alloc ? (unsigned long long *)g.scratch_ptr : (unsigned long long *)g.counters.p;
 
     if (npix > 0) {
         if (max_depth == 0) {
@@ -314,8 +327,13 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             if (d_accum) HIP_TRY(hipMemsetAsync(d_accum, 0, (size_t)npix * 12, g.stream));
             if (d_hit) HIP_TRY(hipMemsetAsync(d_hit, 0xff, (size_t)npix * 4, g.stream));
         } else {
-            HIP_TRY(g.partial.reserve((size_t)units * sizeof(float4)));
-            float4 *d_partial = (float4 *)g.partial.p;
+            float4 *d_partial;
+            if (call.no_alloc) {
+                d_partial = (float4 *)(g.scratch_ptr + kScratchCountersBytes);
+            } else {
+                HIP_TRY(g.partial.reserve((size_t)units * sizeof(float4)));
+                d_partial = (float4 *)g.partial.p;
+            }
             // the counters start at zero; the per-chunk sums need no clearing (every unit writes its sum)
             HIP_TRY(hipMemsetAsync(d_counters, 0, kScratchCountersBytes, g.stream));
 
@@ -467,6 +485,10 @@ int init_ctx(Ctx &g, int device, int count)
     HIP_TRY(hipEventCreate(&g.ev1));
     HIP_TRY(hipEventCreate(&g.ev2));
     HIP_TRY(g.counters.reserve(kScratchCountersBytes));
+    // this device's copy of the static scratch array (each device holds its own, at its own address)
+    void *sp = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)));
+    g.scratch_ptr = (unsigned char *)sp;
     return RT_OK;
 }
 
@@ -600,7 +622,7 @@ int render_on_all(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
 // Common front of the render entry points: state and argument checks that must precede the choice of
 // the unit size, then the single- or multi-context path.
 int render_entry(const char *name, const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height, int spp,
-                 int max_depth, const rt_opts *opts, bool device_ptrs, int64_t frame_index)
+                 int max_depth, const rt_opts *opts, bool device_ptrs, bool no_alloc, int64_t frame_index)
 {
     if (g_nctx == 0) return fail(RT_ERR_STATE, "%s: rt_init has not been called", name);
     if (device_ptrs && g_nctx > 1)
@@ -615,6 +637,7 @@ int render_entry(const char *name, const rt_camera *cam, uint8_t *rgba, uint32_t
     if (g_nctx > 1) return render_on_all(cam, rgba, width, height, spp, max_depth, opts, chunk, frame_index);
     Call call;
     call.device_ptrs = device_ptrs;
+    call.no_alloc = no_alloc;
     call.frame_index = frame_index;
     call.chunk = chunk;
     return render_common(g_ctx[0], cam, rgba, width, height, spp, max_depth, opts, call);
@@ -760,7 +783,7 @@ int rt_render(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t heig
               const rt_opts *opts)
 {
     return guarded("rt_render", [&]() {
-        return render_entry("rt_render", cam, rgba, width, height, spp, max_depth, opts, false, -1);
+        return render_entry("rt_render", cam, rgba, width, height, spp, max_depth, opts, false, false, -1);
     });
 }
 
@@ -768,15 +791,22 @@ int rt_render_device(const rt_camera *cam, uint8_t *rgba_dev, uint32_t width, ui
                      int max_depth, const rt_opts *opts)
 {
     return guarded("rt_render_device", [&]() {
-        return render_entry("rt_render_device", cam, rgba_dev, width, height, spp, max_depth, opts, true, -1);
+        return render_entry("rt_render_device", cam, rgba_dev, width, height, spp, max_depth, opts, true, false, -1);
     });
+}
+
+int rt_render_device_noalloc(const rt_camera *cam, uint8_t *rgba_dev, uint32_t width, uint32_t height, int spp,
+                             int max_depth, const rt_opts *opts)
+{
+    // nothing on this path allocates, so nothing on it throws
+    return render_entry("rt_render_device_noalloc", cam, rgba_dev, width, height, spp, max_depth, opts, true, true, -1);
 }
 
 int rt_render_progressive(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height, int spp,
                           int max_depth, const rt_opts *opts, uint32_t frame_index)
 {
     return guarded("rt_render_progressive", [&]() {
-        return render_entry("rt_render_progressive", cam, rgba, width, height, spp, max_depth, opts, false, (int64_t)frame_index);
+        return render_entry("rt_render_progressive", cam, rgba, width, height, spp, max_depth, opts, false, false, (int64_t)frame_index);
     });
 }
 
