@@ -74,7 +74,8 @@ struct Ctx {
     int nbig = 0;
     int big[kMaxBig] = {0};
     float c_near = 0.0f;
-    DevBuf geom, matA, matB, pairs;
+    DevBuf geom, matA, matB, pairs, aimg;
+    int ntiles = 0;              // 32-sphere tiles of the matrix scan's image (0: the scene is too large for it)
     // scratch
     DevBuf partial, counters, rgba, accum, hit, rows;
     // progressive accumulation (rt_render_progressive): running per-pixel sums and what they belong to
@@ -90,6 +91,7 @@ struct Ctx {
 
 Ctx g_ctx[kMaxContexts];
 int g_nctx = 0;
+bool g_vector_scan = false;      // RTMI_SCAN=vector in the environment at rt_init: packed-FP32 scan for every scene size
 
 thread_local char g_err[512] = "";      // per thread: the worker threads of a multi-device frame report through it
 
@@ -222,6 +224,35 @@ int resolve_chunk(int chunk_opt, uint32_t width, uint32_t height, int spp, bool 
     return chunk;
 }
 
+int scan_variant(const Ctx &g)
+{
+    if (g.ntiles > 0 && !g_vector_scan) return kScanMatrix;
+    return g.n > kMaxSpheresLds ? kScanVectorGlobal : kScanVectorLds;
+}
+
+// bf16 pieces of the matrix scan's sphere image: x = p[0] + p[1] + p[2] exactly (round to nearest even)
+uint16_t bf16_rne(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+float bf16_value(uint16_t b)
+{
+    const uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+void split3(float x, uint16_t p[3])
+{
+    p[0] = bf16_rne(x);
+    const float r1 = x - bf16_value(p[0]);
+    p[1] = bf16_rne(r1);
+    const float r2 = r1 - bf16_value(p[1]);
+    p[2] = bf16_rne(r2);
+}
+
 struct Call {
     bool device_ptrs = false;     // outputs are device pointers (compact over the owned rows)
     bool no_alloc = false;        // partial sums and counters live in the static scratch array; nothing is allocated
@@ -345,6 +376,7 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             tp.cam.defocus_angle = cam->defocus_angle;
             tp.geom = (const float4 *)g.geom.p; tp.matA = (const float4 *)g.matA.p; tp.matB = (const float4 *)g.matB.p;
             tp.pairs = (const float *)g.pairs.p;
+            tp.aimg = (const uint4 *)g.aimg.p; tp.ntiles = g.ntiles;
             tp.n = g.n; tp.n_pad = g.n_pad;
             tp.nbig = g.nbig; memcpy(tp.big, g.big, sizeof tp.big); tp.c_near = g.c_near;
             // one ray over all spheres costs about 9 vector instructions per sphere pair in the scan (for
@@ -366,16 +398,16 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             tp.counters = d_counters;
             tp.total_units = units;
 
-            const bool geom_global = g.n > kMaxSpheresLds;
-            const size_t lds = (geom_global ? 0 : (size_t)g.n_pad * sizeof(float4)) + (size_t)queue_lds_bytes(kBlockThreads, o.strict_fp ? kQueueSlotsStrict : kQueueSlotsFast);
-            const int per_cu = o.strict_fp ? trace_blocks_per_cu_strict(g.launch, geom_global, lds) : trace_blocks_per_cu_fast(g.launch, geom_global, lds);
+            const int variant = scan_variant(g);
+            const size_t lds = trace_lds_bytes(variant, o.strict_fp != 0, g.n_pad, g.ntiles);
+            const int per_cu = o.strict_fp ? trace_blocks_per_cu_strict(g.launch, variant, lds) : trace_blocks_per_cu_fast(g.launch, variant, lds);
             uint64_t blocks = (uint64_t)g.num_cu * (uint64_t)per_cu;
-            const uint64_t need = (units + kBlockThreads - 1) / kBlockThreads;
+            const uint64_t need = (units + block_threads_of(variant) - 1) / block_threads_of(variant);
             if (blocks > need) blocks = need;
 
             HIP_TRY(hipEventRecord(g.ev0, g.stream));
-            HIP_TRY(o.strict_fp ? launch_trace_strict(g.launch, tp, geom_global, (int)blocks, lds, g.stream)
-                                : launch_trace_fast(g.launch, tp, geom_global, (int)blocks, lds, g.stream));
+            HIP_TRY(o.strict_fp ? launch_trace_strict(g.launch, tp, variant, (int)blocks, lds, g.stream)
+                                : launch_trace_fast(g.launch, tp, variant, (int)blocks, lds, g.stream));
             HIP_TRY(hipEventRecord(g.ev1, g.stream));
             ResolveParams rp;
             rp.partial = d_partial; rp.nchunks = nchunks; rp.npix = npix;
@@ -461,6 +493,7 @@ void release_ctx(Ctx &g)
     (void)hipSetDevice(g.device);
     if (g.stream) (void)hipStreamSynchronize(g.stream);
     g.geom.release(); g.matA.release(); g.matB.release(); g.pairs.release();
+    g.aimg.release();
     g.partial.release(); g.running.release(); g.rows.release(); g.counters.release(); g.rgba.release(); g.accum.release(); g.hit.release();
     if (g.ev0) (void)hipEventDestroy(g.ev0);
     if (g.ev1) (void)hipEventDestroy(g.ev1);
@@ -654,6 +687,8 @@ int rt_init_devices(const int *devices, int count)
     return guarded("rt_init", [&]() -> int {
         DeviceGuard keep;
         shutdown_all();
+        const char *scan = getenv("RTMI_SCAN");
+        g_vector_scan = scan && strcmp(scan, "vector") == 0;
         if (!devices || count < 1 || count > kMaxContexts)
             return fail(RT_ERR_ARG, "rt_init_devices: between 1 and %d devices (got %d)", kMaxContexts, count);
         int ndev = 0;
@@ -743,10 +778,48 @@ static int set_world_impl(const rt_sphere *spheres, size_t count)
             q[0] = 0.0f; q[2] = 0.0f; q[4] = 0.0f; q[6] = inf;       // never passes the filter
         }
     }
+    // Matrix scan: per 32-sphere tile the MFMA A fragments of the sphere features (rt_device.h).  K entries
+    // of a sphere: feature f of (cx^2, cy^2, cz^2, cx cy, cx cz, cy cz, cx, cy, cz) at 6 f .. 6 f + 5 as
+    // (c1, c1, c2, c1, c3, c2); 54-56: 1, 1, 1; 57-59: the pieces of k = |C|^2 - r^2; 60-63: 0.
+    // Rows beyond the scene and the big spheres hold k = 3e38 only: their discriminant is -3e38.
+    const int ntiles = n <= kMaxSpheresMatrix ? std::max(1, (n + kTileSpheres - 1) / kTileSpheres) : 0;
+    std::vector<uint16_t> aimg((size_t)ntiles * 4 * 64 * 8, 0);
+    for (int t = 0; t < ntiles; t++)
+        for (int row = 0; row < kTileSpheres; row++) {
+            const int i = t * kTileSpheres + row;
+            uint16_t ent[64];
+            memset(ent, 0, sizeof ent);
+            if (i < n && !is_big[i]) {
+                const double cx = spheres[i].center.x, cy = spheres[i].center.y, cz = spheres[i].center.z;
+                const float feat[9] = {(float)(cx * cx), (float)(cy * cy), (float)(cz * cz), (float)(cx * cy), (float)(cx * cz),
+                                       (float)(cy * cz), (float)cx, (float)cy, (float)cz};
+                for (int f = 0; f < 9; f++) {
+                    uint16_t pc[3];
+                    split3(feat[f], pc);
+                    const uint16_t six[6] = {pc[0], pc[0], pc[1], pc[0], pc[2], pc[1]};
+                    for (int e = 0; e < 6; e++) ent[6 * f + e] = six[e];
+                }
+                ent[54] = ent[55] = ent[56] = bf16_rne(1.0f);
+                uint16_t kp[3];
+                split3((float)(cx * cx + cy * cy + cz * cz - (double)spheres[i].radius * spheres[i].radius), kp);
+                ent[57] = kp[0]; ent[58] = kp[1]; ent[59] = kp[2];
+            } else {
+                ent[57] = bf16_rne(3.0e38f);
+            }
+            for (int s2 = 0; s2 < 4; s2++)
+                for (int hh = 0; hh < 2; hh++)
+                    for (int e = 0; e < 8; e++)
+                        aimg[(((size_t)t * 4 + s2) * 64 + hh * 32 + row) * 8 + e] = ent[16 * s2 + 8 * hh + e];
+        }
     for (int k = 0; k < g_nctx; k++) {
         Ctx &g = g_ctx[k];
         HIP_TRY(hipSetDevice(g.device));
         HIP_TRY(hipStreamSynchronize(g.stream));
+        g.ntiles = ntiles;
+        if (ntiles > 0) {
+            HIP_TRY(g.aimg.reserve(aimg.size() * sizeof(uint16_t)));
+            HIP_TRY(hipMemcpy(g.aimg.p, aimg.data(), aimg.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        }
         HIP_TRY(g.pairs.reserve(pairs.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(g.pairs.p, pairs.data(), pairs.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(g.geom.reserve(geom.size() * sizeof(float4)));
@@ -762,13 +835,12 @@ static int set_world_impl(const rt_sphere *spheres, size_t count)
         g.c_near = (float)c_near;
         // Look up the launch geometry of both builds now (code objects load, LDS attributes are set,
         // occupancy is queried), so that no render call after this one has to.
-        const bool geom_global = n > kMaxSpheresLds;
+        const int variant = scan_variant(g);
         for (int strict = 0; strict < 2; strict++) {
-            const size_t lds = (geom_global ? 0 : (size_t)n_pad * sizeof(float4)) +
-                               (size_t)queue_lds_bytes(kBlockThreads, strict ? kQueueSlotsStrict : kQueueSlotsFast);
+            const size_t lds = trace_lds_bytes(variant, strict != 0, n_pad, ntiles);
             for (int mode = 0; mode < 2; mode++)
-                HIP_TRY(strict ? prepare_trace_strict(g.launch, mode, geom_global, lds) : prepare_trace_fast(g.launch, mode, geom_global, lds));
-            (void)(strict ? trace_blocks_per_cu_strict(g.launch, geom_global, lds) : trace_blocks_per_cu_fast(g.launch, geom_global, lds));
+                HIP_TRY(strict ? prepare_trace_strict(g.launch, mode, variant, lds) : prepare_trace_fast(g.launch, mode, variant, lds));
+            (void)(strict ? trace_blocks_per_cu_strict(g.launch, variant, lds) : trace_blocks_per_cu_fast(g.launch, variant, lds));
         }
     }
     return RT_OK;

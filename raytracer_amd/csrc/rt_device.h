@@ -4,6 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef RT_MAT_THREADS
+#define RT_MAT_THREADS 768
+#endif
+
 namespace rtmi {
 
 // Device-resident world in structure-of-arrays form.  One float4 per sphere and array:
@@ -30,6 +34,25 @@ constexpr int kBlockThreads = 256;
 constexpr int kQueueSlotsFast = 14;        // candidate-queue slots per lane
 constexpr int kQueueSlotsStrict = 16;
 constexpr int queue_lds_bytes(int block_threads, int slots) { return (block_threads / 64) * slots * 64 * 4; }   // waves x slots x 64 lanes x u32
+// The sphere scan comes in three variants.
+//   kScanMatrix       up to kMaxSpheresMatrix spheres: the conservative filter runs on the matrix cores.
+//                     The discriminant of (ray, sphere) with a unit direction d, g = d.O, w = 2 (O - g d) is
+//                         disc = sum_ij (d_i d_j)(c_i c_j) + w.C + (g^2 - |O|^2) - (|C|^2 - r^2),
+//                     one inner product of ten ray features with ten sphere features.  Each f32 feature is
+//                     split exactly into three bf16 pieces x = x1 + x2 + x3 and the six piece products of
+//                     weight >= 2^-16 are summed by v_mfma_f32_32x32x16_bf16 in f32 (K = 9 x 6 + 3 + 3 = 60
+//                     of 64): 32 spheres x 32 rays per 4 instructions; the vector ALU only compares the
+//                     accumulators with zero.  aimg[tile][s][lane] holds the sphere side as MFMA A
+//                     fragments (lane l: sphere 32 tile + (l & 31), K entries 16 s + 8 (l >> 5) ..+7).
+//   kScanVectorLds    packed-FP32 vector scan, per-sphere records in LDS (selectable for comparison)
+//   kScanVectorGlobal packed-FP32 vector scan, per-sphere records from global memory (larger scenes)
+enum { kScanVectorLds = 0, kScanVectorGlobal = 1, kScanMatrix = 2, kScanVariants = 3 };
+constexpr int kTileSpheres = 32;
+constexpr int kMaxTilesMatrix = 18;        // sphere image 4 KB per tile: 72 KB of LDS next to the queues
+constexpr int kMaxSpheresMatrix = kMaxTilesMatrix * kTileSpheres;
+constexpr int kMatBlockThreads = RT_MAT_THREADS;   // one workgroup per CU
+constexpr int kMatSlots = 24;              // candidate-queue slots (u16) per lane and ray half
+constexpr int block_threads_of(int variant) { return variant == kScanMatrix ? kMatBlockThreads : kBlockThreads; }
 constexpr int kMaxSpheresLds = 560;        // up to here the per-sphere records are staged in LDS: 7 workgroups of (9 KB + 14 KB of queues) still fit a CU
 constexpr int kMaxSpheres = 1 << 20;       // beyond kMaxSpheresLds they are read from global memory
 
@@ -44,6 +67,8 @@ struct TraceParams {
     const float4 *matA;                    // [n]
     const float4 *matB;                    // [n]
     const float *pairs;                    // [n_pad / 2][8]
+    const uint4 *aimg;                     // [ntiles][4][64] bf16 fragments of the matrix scan, or nullptr
+    int ntiles;
     int n, n_pad;
     int nbig;                              // spheres tested exactly for every ray
     int big[kMaxBig];
@@ -84,28 +109,38 @@ __host__ __device__ inline uint32_t part_row_at(uint32_t k, int tile_rows, int p
 // The dynamic-LDS attribute and the occupancy answer depend only on (device, kernel, LDS bytes):
 // each device context looks them up once per change of scene size, not once per frame.
 struct LaunchCache {
-    size_t attr_lds[2][2][2];     // [build][mode][geom_global]: LDS size the attribute was last set to
-    size_t occ_lds[2][2];         // [build][geom_global]
-    int occ_blocks[2][2];
+    size_t attr_lds[2][2][kScanVariants];     // [build][mode][variant]: LDS size the attribute was last set to
+    size_t occ_lds[2][kScanVariants];         // [build][variant]
+    int occ_blocks[2][kScanVariants];
     LaunchCache() { reset(); }
     void reset()
     {
         for (int b = 0; b < 2; b++)
-            for (int g = 0; g < 2; g++) {
+            for (int g = 0; g < kScanVariants; g++) {
                 occ_lds[b][g] = (size_t)-1; occ_blocks[b][g] = 1;
                 for (int m = 0; m < 2; m++) attr_lds[b][m][g] = (size_t)-1;
             }
     }
 };
 
-hipError_t launch_trace_strict(LaunchCache &c, const TraceParams &p, bool geom_global, int blocks, size_t lds_bytes, hipStream_t s);
-hipError_t launch_trace_fast(LaunchCache &c, const TraceParams &p, bool geom_global, int blocks, size_t lds_bytes, hipStream_t s);
+hipError_t launch_trace_strict(LaunchCache &c, const TraceParams &p, int variant, int blocks, size_t lds_bytes, hipStream_t s);
+hipError_t launch_trace_fast(LaunchCache &c, const TraceParams &p, int variant, int blocks, size_t lds_bytes, hipStream_t s);
 hipError_t launch_resolve(const ResolveParams &p, hipStream_t s);
-// Sets the dynamic-LDS attribute of the kernel instantiation (mode, geom_global) if it differs from
+// Sets the dynamic-LDS attribute of the kernel instantiation (mode, variant) if it differs from
 // the cached one; the first call per instantiation also makes the runtime load its code object.
-hipError_t prepare_trace_strict(LaunchCache &c, int mode, bool geom_global, size_t lds_bytes);
-hipError_t prepare_trace_fast(LaunchCache &c, int mode, bool geom_global, size_t lds_bytes);
-int trace_blocks_per_cu_strict(LaunchCache &c, bool geom_global, size_t lds_bytes);
-int trace_blocks_per_cu_fast(LaunchCache &c, bool geom_global, size_t lds_bytes);
+hipError_t prepare_trace_strict(LaunchCache &c, int mode, int variant, size_t lds_bytes);
+hipError_t prepare_trace_fast(LaunchCache &c, int mode, int variant, size_t lds_bytes);
+int trace_blocks_per_cu_strict(LaunchCache &c, int variant, size_t lds_bytes);
+int trace_blocks_per_cu_fast(LaunchCache &c, int variant, size_t lds_bytes);
+
+// Dynamic LDS of a trace kernel: [matrix image][geometry image][candidate queues].
+inline size_t trace_lds_bytes(int variant, bool strict, int n_pad, int ntiles)
+{
+    if (variant == kScanMatrix)
+        return (size_t)ntiles * 256 * sizeof(uint4) + (size_t)n_pad * sizeof(float4) +
+               (size_t)(kMatBlockThreads / 64) * 2 * kMatSlots * 64 * sizeof(uint16_t);
+    return (variant == kScanVectorGlobal ? 0 : (size_t)n_pad * sizeof(float4)) +
+           (size_t)queue_lds_bytes(kBlockThreads, strict ? kQueueSlotsStrict : kQueueSlotsFast);
+}
 
 }  // namespace rtmi

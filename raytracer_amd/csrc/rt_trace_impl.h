@@ -353,6 +353,186 @@ __device__ __forceinline__ void scan_spheres(const TraceParams &p, const float4 
     drain(s_geom, queue, cnt, lane, q RT_DIAG_PASS);
 }
 
+// ---- the filter on the matrix cores ---------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// (bf16(lo), bf16(hi)) in one register, round to nearest even (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t bf16_pair(float lo, float hi)
+{
+    const f2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+// x = x1 + x2 + x3 exactly, three bf16 pieces; returns the packed pairs (x1, x2) and (x1, x3)
+__device__ __forceinline__ void split3(float x, uint32_t &p12, uint32_t &p13)
+{
+    const float x1 = __uint_as_float(bf16_pair(x, x) << 16);
+    const float r1 = x - x1;
+    p12 = bf16_pair(x, r1);
+    const float r2 = r1 - __uint_as_float(p12 & 0xffff0000u);
+    p13 = bf16_pair(x, r2);
+}
+
+__device__ __forceinline__ bf16x8 as_frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    return __builtin_bit_cast(bf16x8, make_uint4(a, b, c, d));
+}
+
+// Exact test of the queued candidates of every lane's OWN ray.  An accumulator column is a ray and
+// the two halves of the wave hold different sphere rows of it, so the candidates of the ray of lane l
+// (half h = l >> 5) sit in queue h of lane l and in queue h of lane l ^ 32: queue[(h * kMatSlots + j) * 64 + lane].
+__device__ __forceinline__ void drain_matrix(const float4 *s_geom, const uint16_t *queue, int cnt0, int cnt1, int lane, Probe &q RT_DIAG_ARG)
+{
+#ifdef RT_DIAG
+    const unsigned long long t0 = RT_STAMP();
+#endif
+    const int h = lane >> 5;
+    const auto c = __builtin_amdgcn_permlane32_swap((unsigned)cnt0, (unsigned)cnt1, false, false);
+    // c[0]: lanes < 32 keep their cnt0, lanes >= 32 get cnt1 of lane - 32;  c[1]: lanes < 32 get cnt0 of lane + 32
+    const int mine = h ? (int)c[1] : (int)c[0], theirs = h ? (int)c[0] : (int)c[1];
+    const int total = mine + theirs;
+    const uint16_t *qa = queue + h * (kMatSlots * 64);
+    for (int j = 0; __ballot(j < total) != 0ULL; j++) {
+#ifdef RT_DIAG
+        dg.drain_iters++; dg.drain_lanes += (uint32_t)__popcll(__ballot(j < total));
+#endif
+        if (j < total) {
+            const int i = j < mine ? (int)qa[j * 64 + lane] : (int)qa[(j - mine) * 64 + (lane ^ 32)];
+            exact_test(s_geom, i, q);
+        }
+    }
+#ifdef RT_DIAG
+    dg.t_drain += RT_STAMP() - t0;
+#endif
+}
+
+// One half tile: 16 accumulators per lane = 16 sphere rows of the column's ray.  The common case (no
+// sphere of the tile passes for any ray) costs eight maxima, one compare and one branch.
+__device__ __forceinline__ void queue_passes(const f32x16 &acc, int first, int lane, uint16_t *q, int &cnt, bool &appended RT_DIAG_ARG)
+{
+    const float m0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
+    const float m1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
+    const float m2 = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]);
+    const float m3 = __builtin_fmaxf(__builtin_fmaxf(acc[9], acc[10]), acc[11]);
+    const float m4 = __builtin_fmaxf(__builtin_fmaxf(acc[12], acc[13]), acc[14]);
+    const float m5 = __builtin_fmaxf(__builtin_fmaxf(m0, m1), acc[15]);
+    const float m6 = __builtin_fmaxf(__builtin_fmaxf(m2, m3), m4);
+    const float mx = __builtin_fmaxf(m5, m6);
+    if (__ballot(mx >= 0.0f) != 0ULL) {
+        appended = true;
+#ifdef RT_DIAG
+        dg.branches++;
+#endif
+        if (mx >= 0.0f) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if (acc[i] >= 0.0f) {                        // row (i & 3) + 8 (i >> 2) + 4 (lane >> 5) of the tile
+#ifdef RT_DIAG
+                    dg.passes++;
+#endif
+                    q[cnt * 64 + lane] = (uint16_t)(first + (i & 3) + 8 * (i >> 2));
+                    cnt++;
+                }
+            }
+        }
+    }
+}
+
+// hit() (Main.c:688-713) as matrix filter + exact test; u is the unit direction.
+__device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const float4 *s_geom, const uint4 *s_aimg, uint16_t *queue,
+                                                    int lane, float ux, float uy, float uz, float slack_scale, Probe &q RT_DIAG_ARG)
+{
+#ifdef RT_DIAG
+    const unsigned long long tb0 = RT_STAMP();
+#endif
+    for (int b = 0; b < p.nbig; b++) exact_test(s_geom, p.big[b], q);
+#ifdef RT_DIAG
+    dg.t_big += RT_STAMP() - tb0;
+#endif
+    // ray features: (d_i d_j), w = 2 (O - g d), g^2 - |O|^2 + slack; slack bounds the rounding of the
+    // features, of the dropped piece products, of the accumulation and of the exact test it stands before
+    const float ox = q.ox, oy = q.oy, oz = q.oz;
+    const float oo = fmaf(oz, oz, fmaf(oy, oy, ox * ox));
+    const float reach = __builtin_amdgcn_sqrtf(oo) * 1.0000005f + p.c_near;
+    const float slack = fmaf(reach * reach, slack_scale, 1e-30f);
+    const float g = fmaf(uz, oz, fmaf(uy, oy, ux * ox));
+    float feat[9];
+    feat[0] = ux * ux; feat[1] = uy * uy; feat[2] = uz * uz;
+    feat[3] = 2.0f * ux * uy; feat[4] = 2.0f * ux * uz; feat[5] = 2.0f * uy * uz;
+    feat[6] = 2.0f * fmaf(-g, ux, ox); feat[7] = 2.0f * fmaf(-g, uy, oy); feat[8] = 2.0f * fmaf(-g, uz, oz);
+    const float cst = fmaf(g, g, slack - oo);
+    // K entries of the lane's own ray, two per register: feature f at entries 6 f .. 6 f + 5 as
+    // (x1, x2, x1, x3, x1, x2) against the sphere side's (c1, c1, c2, c1, c3, c2); then the constant
+    // against 1, 1, 1 and -1, -1, -1 against the pieces of k
+    uint32_t R[32];
+#pragma unroll
+    for (int f = 0; f < 9; f++) {
+        split3(feat[f], R[3 * f], R[3 * f + 1]);
+        R[3 * f + 2] = R[3 * f];
+    }
+    {
+        uint32_t c12, c13;
+        split3(cst, c12, c13);
+        R[27] = c12;
+        R[28] = (c13 >> 16) | 0xbf800000u;           // (c3, -1)
+        R[29] = 0xbf80bf80u;                         // (-1, -1)
+        R[30] = 0u; R[31] = 0u;
+    }
+    // B fragments: half H holds rays 32 H .. 32 H + 31 in its columns; lanes 0-31 supply K entries 0-7
+    // of an instruction, lanes 32-63 entries 8-15, of the COLUMN's ray.  One half-swap per register
+    // pair gives both halves' fragments.
+    uint32_t B[2][4][4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; s2++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(R[8 * s2 + v], R[8 * s2 + 4 + v], false, false);
+            B[0][s2][v] = sw[0]; B[1][s2][v] = sw[1];
+        }
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto chain = [&](const bf16x8 (&a)[4], int H) {
+        f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], as_frag(B[H][0][0], B[H][0][1], B[H][0][2], B[H][0][3]), zero, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], as_frag(B[H][1][0], B[H][1][1], B[H][1][2], B[H][1][3]), d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], as_frag(B[H][2][0], B[H][2][1], B[H][2][2], B[H][2][3]), d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[3], as_frag(B[H][3][0], B[H][3][1], B[H][3][2], B[H][3][3]), d, 0, 0, 0);
+        return d;
+    };
+    const int row4 = 4 * (lane >> 5);
+    int cnt0 = 0, cnt1 = 0;
+    bf16x8 a[4], an[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; s2++) a[s2] = __builtin_bit_cast(bf16x8, s_aimg[s2 * 64 + lane]);
+    f32x16 acc0 = chain(a, 0);
+    // software pipeline: the MFMAs of the next half are issued before the compares of the current one
+    for (int t = 0; t < p.ntiles; t++) {
+        f32x16 acc1 = chain(a, 1);
+        const int tn = t + 1 < p.ntiles ? t + 1 : t;
+#pragma unroll
+        for (int s2 = 0; s2 < 4; s2++) an[s2] = __builtin_bit_cast(bf16x8, s_aimg[(tn * 4 + s2) * 64 + lane]);
+        bool appended = false;
+        __builtin_amdgcn_sched_barrier(0);
+        queue_passes(acc0, t * kTileSpheres + row4, lane, queue, cnt0, appended RT_DIAG_PASS);
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = chain(an, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        queue_passes(acc1, t * kTileSpheres + row4, lane, queue + kMatSlots * 64, cnt1, appended RT_DIAG_PASS);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; s2++) a[s2] = an[s2];
+        // a half tile adds at most 16 entries to a queue
+        if (appended && __ballot(cnt0 > kMatSlots - 16 || cnt1 > kMatSlots - 16) != 0ULL) {
+            drain_matrix(s_geom, queue, cnt0, cnt1, lane, q RT_DIAG_PASS);
+            cnt0 = 0; cnt1 = 0;
+        }
+    }
+#ifdef RT_DIAG
+    dg.scans++;
+#endif
+    drain_matrix(s_geom, queue, cnt0, cnt1, lane, q RT_DIAG_PASS);
+}
+
 // hit() for a wave in which only a few lanes still carry a ray (the end of a launch): the 64
 // lanes take one ray at a time, test 64 spheres per step with the exact test and reduce to the
 // nearest hit.  Same candidates, same test, same tie rule as the scan, hence the same result,
@@ -453,16 +633,29 @@ __device__ __forceinline__ void camera_ray(const TraceParams &p, Lane &L)
     set_ray<MODE>(L, org, sub(ps, org));
 }
 
-// GEOM_GLOBAL: scenes whose geometry image does not fit the LDS next to the queues read the
-// per-sphere records (exact test, shading) from global memory through the vector L1 instead.
-template <int MODE, bool GEOM_GLOBAL>
-__global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(const TraceParams p)
+// VARIANT (rt_device.h): kScanMatrix runs the filter on the matrix cores in one large workgroup per CU;
+// kScanVectorGlobal serves scenes whose geometry image does not fit the LDS next to the queues: the
+// per-sphere records (exact test, shading) come from global memory through the vector L1 instead.
+template <int MODE, int VARIANT>
+__global__ __launch_bounds__(VARIANT == kScanMatrix ? kMatBlockThreads : kBlockThreads,
+                             VARIANT == kScanMatrix ? kMatBlockThreads / 256 : RT_MIN_WAVES) void trace_kernel(const TraceParams p)
 {
     extern __shared__ float4 lds[];
     const int lane = (int)__lane_id();
     const float4 *s_geom, *s_matA, *s_matB;
     uint32_t *queue;
-    if (GEOM_GLOBAL) {
+    const uint4 *s_aimg = nullptr;
+    uint16_t *queue16 = nullptr;
+    if (VARIANT == kScanMatrix) {
+        uint4 *img = reinterpret_cast<uint4 *>(lds);                       // [ntiles][4][64]
+        for (int i = threadIdx.x; i < p.ntiles * 256; i += blockDim.x) img[i] = p.aimg[i];
+        float4 *gm = lds + p.ntiles * 256;                                 // [n_pad]
+        for (int i = threadIdx.x; i < p.n_pad; i += blockDim.x) gm[i] = p.geom[i];
+        s_aimg = img; s_geom = gm;
+        s_matA = p.matA; s_matB = p.matB;
+        queue16 = reinterpret_cast<uint16_t *>(gm + p.n_pad) + (threadIdx.x >> 6) * (2 * kMatSlots * 64);
+        queue = nullptr;
+    } else if (VARIANT == kScanVectorGlobal) {
         s_geom = p.geom; s_matA = p.matA; s_matB = p.matB;
         queue = reinterpret_cast<uint32_t *>(lds) + (threadIdx.x >> 6) * (kQueueSlots * 64);
     } else {
@@ -590,6 +783,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(cons
             const float inv = (q.a > 0.0f) ? __builtin_amdgcn_rsqf(q.a) : 0.0f;
             const unsigned long long live = __ballot(active);
             if (__popcll(live) <= p.coop_max) shared_ray_hit(p, s_geom, lane, live, q);
+            else if (VARIANT == kScanMatrix) scan_spheres_matrix(p, s_geom, s_aimg, queue16, lane, q.dx * inv, q.dy * inv, q.dz * inv, 7.6293945e-6f, q RT_DIAG_PASS);
             else scan_spheres(p, s_geom, queue, lane, q.dx * inv, q.dy * inv, q.dz * inv, 7.6293945e-6f, q RT_DIAG_PASS);
             if (!(q.a > 0.0f)) {
                 // a zero or NaN direction gives the filter nothing to work with: test everything
@@ -600,6 +794,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void trace_kernel(cons
 #else
         const unsigned long long live = __ballot(active);
         if (__popcll(live) <= p.coop_max) shared_ray_hit(p, s_geom, lane, live, q);
+        else if (VARIANT == kScanMatrix) scan_spheres_matrix(p, s_geom, s_aimg, queue16, lane, q.dx, q.dy, q.dz, 3.8146973e-6f, q RT_DIAG_PASS);   // 2^-18
         else scan_spheres(p, s_geom, queue, lane, q.dx, q.dy, q.dz, 1.9073486e-6f, q RT_DIAG_PASS);   // 2^-19
 #ifdef RT_DIAG
         if (__popcll(live) <= p.coop_max) dg.shared_rays += (uint32_t)__popcll(live); else dg.scan_lanes += (uint32_t)__popcll(live);

@@ -29,6 +29,9 @@ struct Params {
     int nbatch;
     const float *pairs;       // vector scan: [n_pad/2][8]
     const uint4 *aimg;        // matrix scan: [ntiles][2][64] packed bf16 fragments
+    const uint4 *limg;        // lifted matrix scan: [ntiles][4][64]
+    int reps;                 // timing: the batches are swept this many times
+    unsigned long long *out_branches;   // taken append branches (checked runs)
     int n_pad, ntiles;
     float c_near;
     float slack_scale;
@@ -49,7 +52,9 @@ __global__ __launch_bounds__(256, 7) void scan_vector(const Params p)
     const int nw = gridDim.x * (blockDim.x >> 6);
     uint32_t *queue = lds + (threadIdx.x >> 6) * (kSlots * 64);
     unsigned long long total = 0;
-    for (int b = 0; b < p.nbatch; b++) {
+    unsigned taken = 0;
+    for (int bb = 0; bb < p.nbatch * p.reps; bb++) {
+        const int b = bb % p.nbatch;
         const size_t rid = ((size_t)b * nw + wave) * 64 + lane;
         const Ray r = p.rays[rid];
         const float oo = fmaf(r.oz, r.oz, fmaf(r.oy, r.oy, r.ox * r.ox));
@@ -78,6 +83,7 @@ __global__ __launch_bounds__(256, 7) void scan_vector(const Params p)
                 const f2 e = __builtin_elementwise_fma(h, h, m);
                 const bool px = e.x >= s[6], py = e.y >= s[7];
                 if (__ballot(px || py) != 0ULL) {
+                    if (CHECKED) taken++;
                     if (px) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u)); cnt++; }
                     if (py) { queue[cnt * 64 + lane] = (uint32_t)(2 * (k0 + u) + 1); cnt++; }
                 }
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(256, 7) void scan_vector(const Params p)
         if (CHECKED) { p.out_count[rid] = count; p.out_sum[rid] = sum; }
     }
     for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off);
-    if (lane == 0) atomicAdd(p.out_total, total);
+    if (lane == 0) { atomicAdd(p.out_total, total); if (CHECKED) atomicAdd(p.out_branches, (unsigned long long)taken); }
 }
 
 // ---- the matrix scan ----------------------------------------------------------------------
@@ -137,7 +143,9 @@ __global__ __launch_bounds__(512, 2) void scan_matrix(const Params p)
     __syncthreads();
     const int h = lane >> 5;
     unsigned long long total = 0;
-    for (int b = 0; b < p.nbatch; b++) {
+    unsigned taken = 0;
+    for (int bb = 0; bb < p.nbatch * p.reps; bb++) {
+        const int b = bb % p.nbatch;
         const size_t rid = ((size_t)b * nw + wave) * 64 + lane;
         const Ray r = p.rays[rid];
         const float oo = fmaf(r.oz, r.oz, fmaf(r.oy, r.oy, r.ox * r.ox));
@@ -195,6 +203,7 @@ __global__ __launch_bounds__(512, 2) void scan_matrix(const Params p)
                     const float e0 = fmaf(d1[i], d1[i], d2[i]), e1 = fmaf(d1[i + 1], d1[i + 1], d2[i + 1]);
                     const bool p0 = e0 >= th, p1 = e1 >= th;
                     if (__ballot(p0 || p1) != 0ULL) {
+                        if (CHECKED) taken++;
                         const int row0 = (i & 3) + 8 * (i >> 2) + 4 * h;
                         if (p0) { q[cnt[H] * 64 + lane] = (uint32_t)(t * 32 + row0); cnt[H]++; }
                         if (p1) { q[cnt[H] * 64 + lane] = (uint32_t)(t * 32 + row0 + 1); cnt[H]++; }
@@ -222,7 +231,133 @@ __global__ __launch_bounds__(512, 2) void scan_matrix(const Params p)
         if (CHECKED) { p.out_count[rid] = count; p.out_sum[rid] = sum; }
     }
     for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off);
-    if (lane == 0) atomicAdd(p.out_total, total);
+    if (lane == 0) { atomicAdd(p.out_total, total); if (CHECKED) atomicAdd(p.out_branches, (unsigned long long)taken); }
+}
+
+// ---- the lifted matrix scan -------------------------------------------------------------------
+// The whole discriminant as ONE inner product: with g = d.O and w = 2 (O - g d),
+//   disc + slack = sum_ij (d_i d_j)(c_i c_j) + w.C + (g^2 - |O|^2 + slack) * 1 + (-1) * k.
+// Ten ray features against ten sphere features, each split into three bf16 pieces with the six
+// products of weight >= 2^-16 kept: K = 9 x 6 + 3 + 3 = 60 <= 64, four MFMAs per half, and the vector
+// ALU only compares the accumulator with zero.  The halves are software-pipelined: the MFMAs of the
+// next half are issued before the compares of the current one.
+constexpr int kLSlots = 24;
+
+template <bool CHECKED>
+__device__ __forceinline__ void lifted_process(const f32x16 &acc, int t, int h, int lane, uint16_t *q, int &cnt, unsigned &taken)
+{
+    // fast path: the largest of the sixteen values, one compare, one branch
+    const float m0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
+    const float m1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
+    const float m2 = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]);
+    const float m3 = __builtin_fmaxf(__builtin_fmaxf(acc[9], acc[10]), acc[11]);
+    const float m4 = __builtin_fmaxf(__builtin_fmaxf(acc[12], acc[13]), acc[14]);
+    const float m5 = __builtin_fmaxf(__builtin_fmaxf(m0, m1), acc[15]);
+    const float m6 = __builtin_fmaxf(__builtin_fmaxf(m2, m3), m4);
+    const float mx = __builtin_fmaxf(m5, m6);
+    if (__ballot(mx >= 0.0f) != 0ULL) {
+        if (CHECKED) taken++;
+        if (mx >= 0.0f) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if (acc[i] >= 0.0f) {
+                    q[cnt * 64 + lane] = (uint16_t)(t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h);
+                    cnt++;
+                }
+            }
+        }
+    }
+}
+
+template <bool CHECKED, int THREADS>
+__global__ __launch_bounds__(THREADS, THREADS / 256) void scan_lifted(const Params p)
+{
+    extern __shared__ uint32_t lds[];
+    const int lane = (int)__lane_id();
+    const int wib = threadIdx.x >> 6;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + wib;
+    const int nw = gridDim.x * (blockDim.x >> 6);
+    uint4 *s_a = reinterpret_cast<uint4 *>(lds);                               // [ntiles][4][64]
+    for (int i = threadIdx.x; i < p.ntiles * 256; i += blockDim.x) s_a[i] = p.limg[i];
+    uint16_t *queue = reinterpret_cast<uint16_t *>(lds + p.ntiles * 256 * 4) + wib * (2 * kLSlots * 64);   // [2][kLSlots][64] u16
+    __syncthreads();
+    const int h = lane >> 5;
+    unsigned long long total = 0;
+    unsigned taken = 0;
+    for (int bb = 0; bb < p.nbatch * p.reps; bb++) {
+        const int b = bb % p.nbatch;
+        const size_t rid = ((size_t)b * nw + wave) * 64 + lane;
+        const Ray r = p.rays[rid];
+        const float oo = fmaf(r.oz, r.oz, fmaf(r.oy, r.oy, r.ox * r.ox));
+        const float reach = __builtin_amdgcn_sqrtf(oo) * 1.0000005f + p.c_near;
+        const float slack = fmaf(reach * reach, p.slack_scale, 1e-30f);
+        const float g = fmaf(r.dz, r.oz, fmaf(r.dy, r.oy, r.dx * r.ox));
+        float feat[10];
+        feat[0] = r.dx * r.dx; feat[1] = r.dy * r.dy; feat[2] = r.dz * r.dz;
+        feat[3] = 2.0f * r.dx * r.dy; feat[4] = 2.0f * r.dx * r.dz; feat[5] = 2.0f * r.dy * r.dz;
+        feat[6] = 2.0f * fmaf(-g, r.dx, r.ox); feat[7] = 2.0f * fmaf(-g, r.dy, r.oy); feat[8] = 2.0f * fmaf(-g, r.dz, r.oz);
+        feat[9] = fmaf(g, g, slack - oo);
+        const uint32_t m1 = 0xbf800000u;
+        uint32_t R[32];
+#pragma unroll
+        for (int f = 0; f < 9; f++) {
+            const Split sp = split3(feat[f]);
+            R[3 * f] = pack(sp.p1, sp.p2); R[3 * f + 1] = pack(sp.p1, sp.p3); R[3 * f + 2] = R[3 * f];
+        }
+        {
+            const Split sp = split3(feat[9]);
+            R[27] = pack(sp.p1, sp.p2); R[28] = pack(sp.p3, m1); R[29] = pack(m1, m1); R[30] = 0u; R[31] = 0u;
+        }
+        uint32_t B[2][4][4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; s2++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                auto sw = __builtin_amdgcn_permlane32_swap(R[8 * s2 + v], R[8 * s2 + 4 + v], false, false);
+                B[0][s2][v] = sw[0]; B[1][s2][v] = sw[1];
+            }
+        int cnt[2] = {0, 0};
+        unsigned sum = 0, count = 0;
+        const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        auto chain = [&](const bf16x8 (&a)[4], int H) {
+            f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], frag(B[H][0][0], B[H][0][1], B[H][0][2], B[H][0][3]), zero, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], frag(B[H][1][0], B[H][1][1], B[H][1][2], B[H][1][3]), d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], frag(B[H][2][0], B[H][2][1], B[H][2][2], B[H][2][3]), d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[3], frag(B[H][3][0], B[H][3][1], B[H][3][2], B[H][3][3]), d, 0, 0, 0);
+            return d;
+        };
+        bf16x8 a[4], an[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; s2++) a[s2] = __builtin_bit_cast(bf16x8, s_a[s2 * 64 + lane]);
+        f32x16 acc0 = chain(a, 0);
+        for (int t = 0; t < p.ntiles; t++) {
+            f32x16 acc1 = chain(a, 1);
+            const int tn = t + 1 < p.ntiles ? t + 1 : t;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; s2++) an[s2] = __builtin_bit_cast(bf16x8, s_a[(tn * 4 + s2) * 64 + lane]);
+            __builtin_amdgcn_sched_barrier(0);
+            lifted_process<CHECKED>(acc0, t, h, lane, queue, cnt[0], taken);
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = chain(an, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            lifted_process<CHECKED>(acc1, t, h, lane, queue + kLSlots * 64, cnt[1], taken);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; s2++) a[s2] = an[s2];
+            if (__ballot(cnt[0] > kLSlots - 16 || cnt[1] > kLSlots - 16) != 0ULL || t + 1 == p.ntiles) {
+                auto c = __builtin_amdgcn_permlane32_swap((unsigned)cnt[0], (unsigned)cnt[1], false, false);
+                const int ca = h ? (int)c[1] : (int)c[0], cb = h ? (int)c[0] : (int)c[1];
+                const uint16_t *qa = queue + h * (kLSlots * 64);
+                for (int j = 0; j < ca; j++) { sum += qa[j * 64 + lane]; count++; }
+                for (int j = 0; j < cb; j++) { sum += qa[j * 64 + (lane ^ 32)]; count++; }
+                cnt[0] = 0; cnt[1] = 0;
+            }
+        }
+        total += count;
+        if (CHECKED) { p.out_count[rid] = count; p.out_sum[rid] = sum; }
+    }
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off);
+    if (lane == 0) { atomicAdd(p.out_total, total); if (CHECKED) atomicAdd(p.out_branches, (unsigned long long)taken); }
 }
 
 // ---- host -----------------------------------------------------------------------------------
@@ -297,6 +432,37 @@ int main(int argc, char **argv)
                         aimg[(((size_t)t * 2 + s2) * 64 + hh * 32 + row) * 8 + j] = ent[16 * s2 + 8 * hh + j];
         }
 
+    // lifted image: [tile][s][lane] 8 bf16; 60 K entries: 9 features x 6, then 1,1,1, then k1,k2,k3
+    std::vector<uint16_t> limg((size_t)ntiles * 4 * 64 * 8, 0);
+    for (int t = 0; t < ntiles; t++)
+        for (int row = 0; row < 32; row++) {
+            const int i = t * 32 + row;
+            uint16_t ent[64];
+            memset(ent, 0, sizeof ent);
+            if (i < n && !big[i]) {
+                const double cx = sph[i].c[0], cy = sph[i].c[1], cz = sph[i].c[2];
+                const float feat[9] = {(float)(cx * cx), (float)(cy * cy), (float)(cz * cz), (float)(cx * cy), (float)(cx * cz), (float)(cy * cz),
+                                       (float)cx, (float)cy, (float)cz};
+                for (int c = 0; c < 9; c++) {
+                    uint16_t pc[3];
+                    split3h(feat[c], pc);
+                    const uint16_t six[6] = {pc[0], pc[0], pc[1], pc[0], pc[2], pc[1]};
+                    for (int k = 0; k < 6; k++) ent[6 * c + k] = six[k];
+                }
+                ent[54] = ent[55] = ent[56] = bf16_trunc(1.0f);
+                const float k = (float)(cx * cx + cy * cy + cz * cz - (double)sph[i].r * sph[i].r);
+                uint16_t kp[3];
+                split3h(k, kp);
+                ent[57] = kp[0]; ent[58] = kp[1]; ent[59] = kp[2];
+            } else {
+                ent[57] = bf16_trunc(3.0e38f);
+            }
+            for (int s2 = 0; s2 < 4; s2++)
+                for (int hh = 0; hh < 2; hh++)
+                    for (int j = 0; j < 8; j++)
+                        limg[(((size_t)t * 4 + s2) * 64 + hh * 32 + row) * 8 + j] = ent[16 * s2 + 8 * hh + j];
+        }
+
     // rays: half camera rays, half rays leaving small spheres
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
@@ -307,61 +473,83 @@ int main(int argc, char **argv)
     std::vector<Ray> rays(nrays);
     std::mt19937 rng(12345);
     std::uniform_real_distribution<float> U(0.0f, 1.0f);
-    for (size_t i = 0; i < nrays; i++) {
-        Ray r;
-        float d[3];
-        if (rng() & 1) {
-            r.ox = 13.0f + 0.3f * (U(rng) - 0.5f); r.oy = 2.0f + 0.3f * (U(rng) - 0.5f); r.oz = 3.0f + 0.3f * (U(rng) - 0.5f);
-            float tx = -11.0f + 22.0f * U(rng) * 0.6f, ty = -0.5f + 3.0f * U(rng), tz = -6.0f + 12.0f * U(rng);
-            d[0] = tx - r.ox; d[1] = ty - r.oy; d[2] = tz - r.oz;
-        } else {
-            const Sphere &sp = sph[1 + rng() % (n - 1)];
-            float z = 1 - 2 * U(rng), ph = 6.2831853f * U(rng), rad = sqrtf(std::max(0.0f, 1 - z * z));
-            float nx = rad * cosf(ph), ny = rad * sinf(ph), nz = z;
-            r.ox = sp.c[0] + sp.r * nx; r.oy = sp.c[1] + sp.r * ny; r.oz = sp.c[2] + sp.r * nz;
-            float z2 = 1 - 2 * U(rng), ph2 = 6.2831853f * U(rng), rad2 = sqrtf(std::max(0.0f, 1 - z2 * z2));
-            d[0] = nx + rad2 * cosf(ph2); d[1] = ny + rad2 * sinf(ph2); d[2] = nz + z2;
+    // Rays as the renderer's waves hold them: the 64 lanes of a wave own adjacent pixels.  A wave's rays
+    // are either camera rays through 64 neighbouring pixels, or bounce rays whose origins are the points
+    // those camera rays would hit (close together) with independent random directions.
+    auto unit3 = [](float *d) { float l = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]); if (!(l > 1e-6f)) { d[0] = 0; d[1] = 1; d[2] = 0; l = 1; } d[0] /= l; d[1] /= l; d[2] /= l; };
+    const float px = 0.00138f;                       // pixel pitch at focus distance 10 of the 3840-wide view
+    for (size_t w0 = 0; w0 < nrays; w0 += 64) {
+        const float ax = -9.0f + 16.0f * U(rng), az = -5.0f + 10.0f * U(rng), ay = 0.4f * U(rng);     // aim point near the ground
+        const bool primary = (rng() % 10) < 3;
+        float base_d[3] = {ax - 13.0f, ay - 2.0f, az - 3.0f};
+        const float dist = sqrtf(base_d[0] * base_d[0] + base_d[1] * base_d[1] + base_d[2] * base_d[2]);
+        for (int l = 0; l < 64; l++) {
+            Ray r;
+            float d[3];
+            if (primary) {
+                r.ox = 13.0f + 0.3f * (U(rng) - 0.5f); r.oy = 2.0f + 0.3f * (U(rng) - 0.5f); r.oz = 3.0f + 0.3f * (U(rng) - 0.5f);   // defocus disk
+                const float tx = ax + px * dist / 10.0f * l * 0.3f, tz = az - px * dist / 10.0f * l;
+                d[0] = tx - r.ox; d[1] = ay - r.oy; d[2] = tz - r.oz;
+            } else {
+                r.ox = ax + px * dist / 10.0f * l * 0.3f + 0.02f * (U(rng) - 0.5f); r.oy = ay; r.oz = az - px * dist / 10.0f * l + 0.02f * (U(rng) - 0.5f);
+                const float z = U(rng), ph = 6.2831853f * U(rng), rad = sqrtf(std::max(0.0f, 1 - z * z));
+                d[0] = rad * cosf(ph); d[1] = z + 0.05f; d[2] = rad * sinf(ph);
+            }
+            unit3(d);
+            r.dx = d[0]; r.dy = d[1]; r.dz = d[2];
+            rays[w0 + l] = r;
         }
-        float l = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-        if (!(l > 1e-6f)) { d[0] = 0; d[1] = 1; d[2] = 0; l = 1; }
-        r.dx = d[0] / l; r.dy = d[1] / l; r.dz = d[2] / l;
-        rays[i] = r;
     }
 
     Params p;
     memset(&p, 0, sizeof p);
-    Ray *d_rays; float *d_pairs; uint4 *d_aimg; unsigned *d_cnt, *d_sum; unsigned long long *d_total;
+    Ray *d_rays; float *d_pairs; uint4 *d_aimg, *d_limg; unsigned *d_cnt, *d_sum; unsigned long long *d_total, *d_br;
     CHECK(hipMalloc(&d_rays, nrays * sizeof(Ray)));
     CHECK(hipMalloc(&d_pairs, pairs.size() * 4));
     CHECK(hipMalloc(&d_aimg, aimg.size() * 2));
     CHECK(hipMalloc(&d_cnt, nrays * 4));
     CHECK(hipMalloc(&d_sum, nrays * 4));
     CHECK(hipMalloc(&d_total, 8));
+    CHECK(hipMalloc(&d_br, 8));
+    CHECK(hipMalloc(&d_limg, limg.size() * 2));
+    CHECK(hipMemcpy(d_limg, limg.data(), limg.size() * 2, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_rays, rays.data(), nrays * sizeof(Ray), hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_pairs, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_aimg, aimg.data(), aimg.size() * 2, hipMemcpyHostToDevice));
     p.rays = d_rays; p.nbatch = nbatch; p.pairs = d_pairs; p.aimg = d_aimg; p.n_pad = n_pad; p.ntiles = ntiles;
-    p.c_near = (float)c_near; p.out_count = d_cnt; p.out_sum = d_sum; p.out_total = d_total;
+    p.c_near = (float)c_near; p.out_count = d_cnt; p.out_sum = d_sum; p.out_total = d_total; p.out_branches = d_br; p.limg = d_limg; p.reps = 1;
 
     const size_t lds_v = 4 * kSlots * 64 * 4;
     const size_t lds_m = (size_t)ntiles * 128 * 16 + 8 * 2 * kSlots * 64 * 4;
     CHECK(hipFuncSetAttribute((const void *)scan_matrix<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
     CHECK(hipFuncSetAttribute((const void *)scan_matrix<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+    const size_t lds_l = (size_t)ntiles * 256 * 16 + 8 * 2 * kLSlots * 64 * 2;
+    const size_t lds_l4 = (size_t)ntiles * 256 * 16 + 16 * 2 * kLSlots * 64 * 2;
+    CHECK(hipFuncSetAttribute((const void *)scan_lifted<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
+    CHECK(hipFuncSetAttribute((const void *)scan_lifted<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
+    CHECK(hipFuncSetAttribute((const void *)scan_lifted<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l4));
 
     // ---- check: candidate sets
-    std::vector<unsigned> cv(nrays), sv(nrays), cm(nrays), sm(nrays);
-    const size_t ncheck = (size_t)waves_m * 64;           // first batch of the matrix kernel's wave count
-    for (int which = 0; which < 2; which++) {
+    const size_t ncheck = (size_t)waves_m * 64;           // first batch, at the matrix kernels' wave count
+    std::vector<unsigned> cnts[3], sums[3];
+    unsigned long long branches[3] = {0, 0, 0};
+    const char *names[3] = {"vector", "matrix", "lifted"};
+    const float slacks[3] = {1.9073486e-6f, 3.8146973e-6f, 3.8146973e-6f};     // 2^-19, 2^-18, 2^-18
+    for (int which = 0; which < 3; which++) {
+        cnts[which].resize(ncheck); sums[which].resize(ncheck);
         CHECK(hipMemset(d_cnt, 0xff, nrays * 4));
         CHECK(hipMemset(d_total, 0, 8));
-        Params q = p; q.nbatch = 1;
-        if (which == 0) { q.slack_scale = 1.9073486e-6f; hipLaunchKernelGGL(scan_vector<true>, dim3(waves_m / 4), dim3(256), lds_v, 0, q); }
-        else { q.slack_scale = 3.8146973e-6f; hipLaunchKernelGGL(scan_matrix<true>, dim3(waves_m / 8), dim3(512), lds_m, 0, q); }
+        CHECK(hipMemset(d_br, 0, 8));
+        Params q = p; q.nbatch = 1; q.reps = 1; q.slack_scale = slacks[which];
+        if (which == 0) hipLaunchKernelGGL(scan_vector<true>, dim3(waves_m / 4), dim3(256), lds_v, 0, q);
+        else if (which == 1) hipLaunchKernelGGL(scan_matrix<true>, dim3(waves_m / 8), dim3(512), lds_m, 0, q);
+        else hipLaunchKernelGGL((scan_lifted<true, 512>), dim3(waves_m / 8), dim3(512), lds_l, 0, q);
         CHECK(hipDeviceSynchronize());
-        CHECK(hipMemcpy(which ? cm.data() : cv.data(), d_cnt, ncheck * 4, hipMemcpyDeviceToHost));
-        CHECK(hipMemcpy(which ? sm.data() : sv.data(), d_sum, ncheck * 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(cnts[which].data(), d_cnt, ncheck * 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(sums[which].data(), d_sum, ncheck * 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(&branches[which], d_br, 8, hipMemcpyDeviceToHost));
     }
-    size_t exact_total = 0, vec_total = 0, mat_total = 0, mat_missing = 0, vec_missing = 0;
+    size_t exact_total = 0, tot[3] = {0, 0, 0}, missing[3] = {0, 0, 0};
     for (size_t i = 0; i < ncheck; i++) {
         const Ray &r = rays[i];
         unsigned ec = 0, es = 0;
@@ -372,32 +560,41 @@ int main(int argc, char **argv)
             double disc = hh * hh - (ocx * ocx + ocy * ocy + ocz * ocz - (double)sph[k].r * sph[k].r);
             if (disc >= 0) { ec++; es += k; }
         }
-        exact_total += ec; vec_total += cv[i]; mat_total += cm[i];
+        exact_total += ec;
         // a superset with equal size and equal index sum is the same set; a smaller set lost a sphere
-        if (cm[i] < ec || (cm[i] == ec && sm[i] != es)) mat_missing++;
-        if (cv[i] < ec || (cv[i] == ec && sv[i] != es)) vec_missing++;
+        for (int w = 0; w < 3; w++) {
+            tot[w] += cnts[w][i];
+            if (cnts[w][i] < ec || (cnts[w][i] == ec && sums[w][i] != es)) missing[w]++;
+        }
     }
-    printf("check over %zu rays: exact candidates %.3f per ray; vector filter %.3f (rays with a lost sphere: %zu); matrix filter %.3f (rays with a lost sphere: %zu)\n",
-           ncheck, (double)exact_total / ncheck, (double)vec_total / ncheck, vec_missing, (double)mat_total / ncheck, mat_missing);
+    printf("check over %zu rays: exact candidates %.3f per ray\n", ncheck, (double)exact_total / ncheck);
+    for (int w = 0; w < 3; w++)
+        printf("  %s filter: %.3f candidates per ray, rays with a lost sphere: %zu, append branches taken per wave scan: %.1f\n",
+               names[w], (double)tot[w] / ncheck, missing[w], (double)branches[w] / (double)waves_m);
 
     // ---- timing
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    for (int which = 0; which < 2; which++) {
+    const int reps = argc > 3 ? atoi(argv[3]) : 10;
+    const char *tnames[4] = {"vector", "matrix", "lifted 2 waves/SIMD", "lifted 4 waves/SIMD"};
+    for (int which = 0; which < 4; which++) {
         Params q = p;
-        q.slack_scale = which ? 3.8146973e-6f : 1.9073486e-6f;
-        const int waves = which ? waves_m : waves_v;
+        q.slack_scale = slacks[which < 3 ? which : 2];
+        q.reps = reps;
+        const int waves = which == 0 ? waves_v : (which == 3 ? 2 * waves_m : waves_m);
         for (int rep = 0; rep < 3; rep++) {
             CHECK(hipEventRecord(e0));
             if (which == 0) hipLaunchKernelGGL(scan_vector<false>, dim3(waves / 4), dim3(256), lds_v, 0, q);
-            else hipLaunchKernelGGL(scan_matrix<false>, dim3(waves / 8), dim3(512), lds_m, 0, q);
+            else if (which == 1) hipLaunchKernelGGL(scan_matrix<false>, dim3(waves / 8), dim3(512), lds_m, 0, q);
+            else if (which == 2) hipLaunchKernelGGL((scan_lifted<false, 512>), dim3(waves / 8), dim3(512), lds_l, 0, q);
+            else hipLaunchKernelGGL((scan_lifted<false, 1024>), dim3(waves / 16), dim3(1024), lds_l4, 0, q);
             CHECK(hipEventRecord(e1));
             CHECK(hipDeviceSynchronize());
             float ms = 0;
             CHECK(hipEventElapsedTime(&ms, e0, e1));
-            const double tests = (double)nbatch * waves * 64 * n;
-            printf("%s scan: %d waves x %d batches: %.3f ms, %.2f G tests/s, algorithmic %.1f TFLOP/s = %.3f of the vector peak\n",
-                   which ? "matrix" : "vector", waves, nbatch, ms, tests / ms / 1e6, 18.0 * tests / ms / 1e9, 18.0 * tests / ms / 1e9 / 157.3);
+            const double tests = (double)nbatch * reps * waves * 64 * n;
+            printf("%s scan: %d waves x %d batches x %d: %.3f ms, %.2f G tests/s, algorithmic %.1f TFLOP/s = %.3f of the vector peak\n",
+                   tnames[which], waves, nbatch, reps, ms, tests / ms / 1e6, 18.0 * tests / ms / 1e9, 18.0 * tests / ms / 1e9 / 157.3);
         }
     }
     return 0;
