@@ -377,6 +377,7 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             tp.geom = (const float4 *)g.geom.p; tp.matA = (const float4 *)g.matA.p; tp.matB = (const float4 *)g.matB.p;
             tp.pairs = (const float *)g.pairs.p;
             tp.aimg = (const uint4 *)g.aimg.p; tp.ntiles = g.ntiles;
+            tp.mat_slots = mat_slots(g.n_pad, g.ntiles);
             tp.n = g.n; tp.n_pad = g.n_pad;
             tp.nbig = g.nbig; memcpy(tp.big, g.big, sizeof tp.big); tp.c_near = g.c_near;
             // one ray over all spheres costs about 9 vector instructions per sphere pair in the scan (for
@@ -782,7 +783,8 @@ static int set_world_impl(const rt_sphere *spheres, size_t count)
     // of a sphere: feature f of (cx^2, cy^2, cz^2, cx cy, cx cz, cy cz, cx, cy, cz) at 6 f .. 6 f + 5 as
     // (c1, c1, c2, c1, c3, c2); 54-56: 1, 1, 1; 57-59: the pieces of k = |C|^2 - r^2; 60-63: 0.
     // Rows beyond the scene and the big spheres hold k = 3e38 only: their discriminant is -3e38.
-    const int ntiles = n <= kMaxSpheresMatrix ? std::max(1, (n + kTileSpheres - 1) / kTileSpheres) : 0;
+    int ntiles = n <= kMaxSpheresMatrix ? std::max(1, (n + kTileSpheres - 1) / kTileSpheres) : 0;
+    if (ntiles > 0 && mat_slots(n_pad, ntiles) < kMatSlotsMin) ntiles = 0;      // no room for the queues: vector scan
     std::vector<uint16_t> aimg((size_t)ntiles * 4 * 64 * 8, 0);
     for (int t = 0; t < ntiles; t++)
         for (int row = 0; row < kTileSpheres; row++) {

@@ -5,7 +5,7 @@
 #include <stdint.h>
 
 #ifndef RT_MAT_THREADS
-#define RT_MAT_THREADS 768
+#define RT_MAT_THREADS 1024
 #endif
 
 namespace rtmi {
@@ -50,8 +50,17 @@ enum { kScanVectorLds = 0, kScanVectorGlobal = 1, kScanMatrix = 2, kScanVariants
 constexpr int kTileSpheres = 32;
 constexpr int kMaxTilesMatrix = 18;        // sphere image 4 KB per tile: 72 KB of LDS next to the queues
 constexpr int kMaxSpheresMatrix = kMaxTilesMatrix * kTileSpheres;
-constexpr int kMatBlockThreads = RT_MAT_THREADS;   // one workgroup per CU
-constexpr int kMatSlots = 24;              // candidate-queue slots (u16) per lane and ray half
+constexpr int kMatBlockThreads = RT_MAT_THREADS;   // one workgroup per CU: 4 waves per SIMD at 128 VGPRs
+constexpr int kLdsBytes = 160 * 1024;
+// candidate-queue slots (u16) per lane and ray half: what the LDS leaves next to the two images, at least
+// kMatSlotsMin (a half tile can add 16 entries to a queue: it is drained once a lane holds more than slots - 16)
+constexpr int kMatSlotsMin = 18, kMatSlotsMax = 32;
+inline int mat_slots(int n_pad, int ntiles)
+{
+    const long room = (long)kLdsBytes - (long)ntiles * 256 * 16 - (long)n_pad * 16;
+    const long s = room / ((kMatBlockThreads / 64) * 2 * 64 * 2);
+    return (int)(s > kMatSlotsMax ? kMatSlotsMax : s);
+}
 constexpr int block_threads_of(int variant) { return variant == kScanMatrix ? kMatBlockThreads : kBlockThreads; }
 constexpr int kMaxSpheresLds = 560;        // up to here the per-sphere records are staged in LDS: 7 workgroups of (9 KB + 14 KB of queues) still fit a CU
 constexpr int kMaxSpheres = 1 << 20;       // beyond kMaxSpheresLds they are read from global memory
@@ -69,6 +78,7 @@ struct TraceParams {
     const float *pairs;                    // [n_pad / 2][8]
     const uint4 *aimg;                     // [ntiles][4][64] bf16 fragments of the matrix scan, or nullptr
     int ntiles;
+    int mat_slots;                         // queue slots per lane and ray half (matrix scan)
     int n, n_pad;
     int nbig;                              // spheres tested exactly for every ray
     int big[kMaxBig];
@@ -138,7 +148,7 @@ inline size_t trace_lds_bytes(int variant, bool strict, int n_pad, int ntiles)
 {
     if (variant == kScanMatrix)
         return (size_t)ntiles * 256 * sizeof(uint4) + (size_t)n_pad * sizeof(float4) +
-               (size_t)(kMatBlockThreads / 64) * 2 * kMatSlots * 64 * sizeof(uint16_t);
+               (size_t)(kMatBlockThreads / 64) * 2 * mat_slots(n_pad, ntiles) * 64 * sizeof(uint16_t);
     return (variant == kScanVectorGlobal ? 0 : (size_t)n_pad * sizeof(float4)) +
            (size_t)queue_lds_bytes(kBlockThreads, strict ? kQueueSlotsStrict : kQueueSlotsFast);
 }

@@ -382,8 +382,8 @@ __device__ __forceinline__ bf16x8 as_frag(uint32_t a, uint32_t b, uint32_t c, ui
 
 // Exact test of the queued candidates of every lane's OWN ray.  An accumulator column is a ray and
 // the two halves of the wave hold different sphere rows of it, so the candidates of the ray of lane l
-// (half h = l >> 5) sit in queue h of lane l and in queue h of lane l ^ 32: queue[(h * kMatSlots + j) * 64 + lane].
-__device__ __forceinline__ void drain_matrix(const float4 *s_geom, const uint16_t *queue, int cnt0, int cnt1, int lane, Probe &q RT_DIAG_ARG)
+// (half h = l >> 5) sit in queue h of lane l and in queue h of lane l ^ 32: queue[(h * slots + j) * 64 + lane].
+__device__ __forceinline__ void drain_matrix(const float4 *s_geom, const uint16_t *queue, int slots, int cnt0, int cnt1, int lane, Probe &q RT_DIAG_ARG)
 {
 #ifdef RT_DIAG
     const unsigned long long t0 = RT_STAMP();
@@ -393,7 +393,7 @@ __device__ __forceinline__ void drain_matrix(const float4 *s_geom, const uint16_
     // c[0]: lanes < 32 keep their cnt0, lanes >= 32 get cnt1 of lane - 32;  c[1]: lanes < 32 get cnt0 of lane + 32
     const int mine = h ? (int)c[1] : (int)c[0], theirs = h ? (int)c[0] : (int)c[1];
     const int total = mine + theirs;
-    const uint16_t *qa = queue + h * (kMatSlots * 64);
+    const uint16_t *qa = queue + h * (slots * 64);
     for (int j = 0; __ballot(j < total) != 0ULL; j++) {
 #ifdef RT_DIAG
         dg.drain_iters++; dg.drain_lanes += (uint32_t)__popcll(__ballot(j < total));
@@ -425,18 +425,22 @@ __device__ __forceinline__ void queue_passes(const f32x16 &acc, int first, int l
 #ifdef RT_DIAG
         dg.branches++;
 #endif
-        if (mx >= 0.0f) {
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                if (acc[i] >= 0.0f) {                        // row (i & 3) + 8 (i >> 2) + 4 (lane >> 5) of the tile
+        // the group maxima say where to look: five groups of three rows and the last row
+        auto put = [&](int i) {
+            if (acc[i] >= 0.0f) {                            // row (i & 3) + 8 (i >> 2) + 4 (lane >> 5) of the tile
 #ifdef RT_DIAG
-                    dg.passes++;
+                dg.passes++;
 #endif
-                    q[cnt * 64 + lane] = (uint16_t)(first + (i & 3) + 8 * (i >> 2));
-                    cnt++;
-                }
+                q[cnt * 64 + lane] = (uint16_t)(first + (i & 3) + 8 * (i >> 2));
+                cnt++;
             }
-        }
+        };
+        if (__ballot(m0 >= 0.0f) != 0ULL) { put(0); put(1); put(2); }
+        if (__ballot(m1 >= 0.0f) != 0ULL) { put(3); put(4); put(5); }
+        if (__ballot(m2 >= 0.0f) != 0ULL) { put(6); put(7); put(8); }
+        if (__ballot(m3 >= 0.0f) != 0ULL) { put(9); put(10); put(11); }
+        if (__ballot(m4 >= 0.0f) != 0ULL) { put(12); put(13); put(14); }
+        put(15);
     }
 }
 
@@ -500,6 +504,7 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
         return d;
     };
     const int row4 = 4 * (lane >> 5);
+    const int slots = p.mat_slots;
     int cnt0 = 0, cnt1 = 0;
     bf16x8 a[4], an[4];
 #pragma unroll
@@ -517,20 +522,20 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
         __builtin_amdgcn_sched_barrier(0);
         acc0 = chain(an, 0);
         __builtin_amdgcn_sched_barrier(0);
-        queue_passes(acc1, t * kTileSpheres + row4, lane, queue + kMatSlots * 64, cnt1, appended RT_DIAG_PASS);
+        queue_passes(acc1, t * kTileSpheres + row4, lane, queue + slots * 64, cnt1, appended RT_DIAG_PASS);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s2 = 0; s2 < 4; s2++) a[s2] = an[s2];
         // a half tile adds at most 16 entries to a queue
-        if (appended && __ballot(cnt0 > kMatSlots - 16 || cnt1 > kMatSlots - 16) != 0ULL) {
-            drain_matrix(s_geom, queue, cnt0, cnt1, lane, q RT_DIAG_PASS);
+        if (appended && __ballot(cnt0 > slots - 16 || cnt1 > slots - 16) != 0ULL) {
+            drain_matrix(s_geom, queue, slots, cnt0, cnt1, lane, q RT_DIAG_PASS);
             cnt0 = 0; cnt1 = 0;
         }
     }
 #ifdef RT_DIAG
     dg.scans++;
 #endif
-    drain_matrix(s_geom, queue, cnt0, cnt1, lane, q RT_DIAG_PASS);
+    drain_matrix(s_geom, queue, slots, cnt0, cnt1, lane, q RT_DIAG_PASS);
 }
 
 // hit() for a wave in which only a few lanes still carry a ray (the end of a launch): the 64
@@ -653,7 +658,7 @@ __global__ __launch_bounds__(VARIANT == kScanMatrix ? kMatBlockThreads : kBlockT
         for (int i = threadIdx.x; i < p.n_pad; i += blockDim.x) gm[i] = p.geom[i];
         s_aimg = img; s_geom = gm;
         s_matA = p.matA; s_matB = p.matB;
-        queue16 = reinterpret_cast<uint16_t *>(gm + p.n_pad) + (threadIdx.x >> 6) * (2 * kMatSlots * 64);
+        queue16 = reinterpret_cast<uint16_t *>(gm + p.n_pad) + (threadIdx.x >> 6) * (2 * p.mat_slots * 64);
         queue = nullptr;
     } else if (VARIANT == kScanVectorGlobal) {
         s_geom = p.geom; s_matA = p.matA; s_matB = p.matB;

@@ -30,6 +30,9 @@ struct Params {
     const float *pairs;       // vector scan: [n_pad/2][8]
     const uint4 *aimg;        // matrix scan: [ntiles][2][64] packed bf16 fragments
     const uint4 *limg;        // lifted matrix scan: [ntiles][4][64]
+    const uint4 *himg;        // f16 x 2 lifted scan: [ntiles][2][64]
+    float scale;              // f16 scan: power-of-two scene scale
+    float *dump;              // calibration: accumulator (discriminant, no slack) per (ray of wave 0.., sphere)
     int reps;                 // timing: the batches are swept this many times
     unsigned long long *out_branches;   // taken append branches (checked runs)
     int n_pad, ntiles;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void scan_lifted(const Para
         feat[0] = r.dx * r.dx; feat[1] = r.dy * r.dy; feat[2] = r.dz * r.dz;
         feat[3] = 2.0f * r.dx * r.dy; feat[4] = 2.0f * r.dx * r.dz; feat[5] = 2.0f * r.dy * r.dz;
         feat[6] = 2.0f * fmaf(-g, r.dx, r.ox); feat[7] = 2.0f * fmaf(-g, r.dy, r.oy); feat[8] = 2.0f * fmaf(-g, r.dz, r.oz);
-        feat[9] = fmaf(g, g, slack - oo);
+        feat[9] = fmaf(g, g, ((CHECKED && p.dump) ? 0.0f : slack) - oo);
         const uint32_t m1 = 0xbf800000u;
         uint32_t R[32];
 #pragma unroll
@@ -335,6 +338,13 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void scan_lifted(const Para
             const int tn = t + 1 < p.ntiles ? t + 1 : t;
 #pragma unroll
             for (int s2 = 0; s2 < 4; s2++) an[s2] = __builtin_bit_cast(bf16x8, s_a[(tn * 4 + s2) * 64 + lane]);
+            if (CHECKED && p.dump) {
+                for (int i = 0; i < 16; i++) {
+                    const int row = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    p.dump[((size_t)wave * 64 + (lane & 31)) * (p.ntiles * 32) + row] = acc0[i];
+                    p.dump[((size_t)wave * 64 + 32 + (lane & 31)) * (p.ntiles * 32) + row] = acc1[i];
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             lifted_process<CHECKED>(acc0, t, h, lane, queue, cnt[0], taken);
             __builtin_amdgcn_sched_barrier(0);
@@ -344,6 +354,126 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void scan_lifted(const Para
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s2 = 0; s2 < 4; s2++) a[s2] = an[s2];
+            if (__ballot(cnt[0] > kLSlots - 16 || cnt[1] > kLSlots - 16) != 0ULL || t + 1 == p.ntiles) {
+                auto c = __builtin_amdgcn_permlane32_swap((unsigned)cnt[0], (unsigned)cnt[1], false, false);
+                const int ca = h ? (int)c[1] : (int)c[0], cb = h ? (int)c[0] : (int)c[1];
+                const uint16_t *qa = queue + h * (kLSlots * 64);
+                for (int j = 0; j < ca; j++) { sum += qa[j * 64 + lane]; count++; }
+                for (int j = 0; j < cb; j++) { sum += qa[j * 64 + (lane ^ 32)]; count++; }
+                cnt[0] = 0; cnt[1] = 0;
+            }
+        }
+        total += count;
+        if (CHECKED) { p.out_count[rid] = count; p.out_sum[rid] = sum; }
+    }
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off);
+    if (lane == 0) { atomicAdd(p.out_total, total); if (CHECKED) atomicAdd(p.out_branches, (unsigned long long)taken); }
+}
+
+// ---- the lifted scan with f16 x 2 pieces ----------------------------------------------------------
+// Same inner product in a frame scaled by a power of two s (spheres within 128 of the origin): every
+// feature x = x1 + x2 (+ 2^-24 |x|) as two f16 pieces, products x1 y1 + x1 y2 + x2 y1 kept:
+// K = 9 x 3 + 2 + 2 = 31 of 32, two v_mfma_f32_32x32x16_f16 per half.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t packh(_Float16 lo, _Float16 hi) { const h2 v = {lo, hi}; return __builtin_bit_cast(uint32_t, v); }
+
+__device__ __forceinline__ h8 hfrag(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    uint4 v = make_uint4(a, b, c, d);
+    return __builtin_bit_cast(h8, v);
+}
+
+template <bool CHECKED, int THREADS, bool DUMP>
+__global__ __launch_bounds__(THREADS, THREADS / 256) void scan_f16(const Params p)
+{
+    extern __shared__ uint32_t lds[];
+    const int lane = (int)__lane_id();
+    const int wib = threadIdx.x >> 6;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + wib;
+    const int nw = gridDim.x * (blockDim.x >> 6);
+    uint4 *s_a = reinterpret_cast<uint4 *>(lds);                               // [ntiles][2][64]
+    for (int i = threadIdx.x; i < p.ntiles * 128; i += blockDim.x) s_a[i] = p.himg[i];
+    uint16_t *queue = reinterpret_cast<uint16_t *>(lds + p.ntiles * 128 * 4) + wib * (2 * kLSlots * 64);
+    __syncthreads();
+    const int h = lane >> 5;
+    unsigned long long total = 0;
+    unsigned taken = 0;
+    for (int bb = 0; bb < p.nbatch * p.reps; bb++) {
+        const int b = bb % p.nbatch;
+        const size_t rid = ((size_t)b * nw + wave) * 64 + lane;
+        const Ray r = p.rays[rid];
+        const float ox = r.ox * p.scale, oy = r.oy * p.scale, oz = r.oz * p.scale;
+        const float oo = fmaf(oz, oz, fmaf(oy, oy, ox * ox));
+        const float reach = __builtin_amdgcn_sqrtf(oo) * 1.0000005f + p.c_near * p.scale;
+        const float slack = DUMP ? 0.0f : fmaf(reach * reach, p.slack_scale, 0.004f);
+        const float g = fmaf(r.dz, oz, fmaf(r.dy, oy, r.dx * ox));
+        float feat[10];
+        feat[0] = r.dx * r.dx; feat[1] = r.dy * r.dy; feat[2] = r.dz * r.dz;
+        feat[3] = 2.0f * r.dx * r.dy; feat[4] = 2.0f * r.dx * r.dz; feat[5] = 2.0f * r.dy * r.dz;
+        feat[6] = 2.0f * fmaf(-g, r.dx, ox); feat[7] = 2.0f * fmaf(-g, r.dy, oy); feat[8] = 2.0f * fmaf(-g, r.dz, oz);
+        feat[9] = fmaf(g, g, slack - oo);
+        _Float16 x1[10], x2[10];
+#pragma unroll
+        for (int f = 0; f < 10; f++) {
+            x1[f] = (_Float16)feat[f];
+            x2[f] = (_Float16)(feat[f] - (float)x1[f]);
+        }
+        const _Float16 m1 = (_Float16)-1.0f, z0 = (_Float16)0.0f;
+        uint32_t R[16];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {                 // features 2k, 2k+1 fill three registers
+            R[3 * k] = packh(x1[2 * k], x2[2 * k]);
+            R[3 * k + 1] = packh(x1[2 * k], x1[2 * k + 1]);
+            R[3 * k + 2] = packh(x2[2 * k + 1], x1[2 * k + 1]);
+        }
+        R[12] = packh(x1[8], x2[8]);
+        R[13] = packh(x1[8], x1[9]);
+        R[14] = packh(x2[9], m1);
+        R[15] = packh(m1, z0);
+        uint32_t B[2][2][4];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                auto sw = __builtin_amdgcn_permlane32_swap(R[8 * s2 + v], R[8 * s2 + 4 + v], false, false);
+                B[0][s2][v] = sw[0]; B[1][s2][v] = sw[1];
+            }
+        int cnt[2] = {0, 0};
+        unsigned sum = 0, count = 0;
+        const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        auto chain = [&](const h8 (&a)[2], int H) {
+            f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], hfrag(B[H][0][0], B[H][0][1], B[H][0][2], B[H][0][3]), zero, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], hfrag(B[H][1][0], B[H][1][1], B[H][1][2], B[H][1][3]), d, 0, 0, 0);
+            return d;
+        };
+        h8 a[2], an[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) a[s2] = __builtin_bit_cast(h8, s_a[s2 * 64 + lane]);
+        f32x16 acc0 = chain(a, 0);
+        for (int t = 0; t < p.ntiles; t++) {
+            f32x16 acc1 = chain(a, 1);
+            const int tn = t + 1 < p.ntiles ? t + 1 : t;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) an[s2] = __builtin_bit_cast(h8, s_a[(tn * 2 + s2) * 64 + lane]);
+            if (DUMP) {
+                // column = ray 32 H + (lane & 31) of this wave; row = sphere 32 t + (i & 3) + 8 (i >> 2) + 4 h
+                for (int i = 0; i < 16; i++) {
+                    const int row = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    p.dump[((size_t)wave * 64 + (lane & 31)) * (p.ntiles * 32) + row] = acc0[i];
+                    p.dump[((size_t)wave * 64 + 32 + (lane & 31)) * (p.ntiles * 32) + row] = acc1[i];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            lifted_process<CHECKED>(acc0, t, h, lane, queue, cnt[0], taken);
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = chain(an, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            lifted_process<CHECKED>(acc1, t, h, lane, queue + kLSlots * 64, cnt[1], taken);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) a[s2] = an[s2];
             if (__ballot(cnt[0] > kLSlots - 16 || cnt[1] > kLSlots - 16) != 0ULL || t + 1 == p.ntiles) {
                 auto c = __builtin_amdgcn_permlane32_swap((unsigned)cnt[0], (unsigned)cnt[1], false, false);
                 const int ca = h ? (int)c[1] : (int)c[0], cb = h ? (int)c[0] : (int)c[1];
@@ -473,6 +603,39 @@ int main(int argc, char **argv)
     std::vector<Ray> rays(nrays);
     std::mt19937 rng(12345);
     std::uniform_real_distribution<float> U(0.0f, 1.0f);
+    // f16 image: scene scaled by a power of two so that every filtered sphere lies within 128 of the origin
+    double max_ext = 0;
+    for (int i = 0; i < n; i++) if (!big[i]) max_ext = std::max(max_ext, ext[i]);
+    const float scale = max_ext > 0 ? (float)std::exp2(std::floor(std::log2(128.0 / max_ext))) : 1.0f;
+    printf("scene scale %g (largest filtered extent %.2f)\n", scale, max_ext);
+    std::vector<uint16_t> himg((size_t)ntiles * 2 * 64 * 8, 0);
+    auto h16 = [](float x) { _Float16 hx = (_Float16)x; uint16_t u; memcpy(&u, &hx, 2); return u; };
+    auto h16v = [](float x) { return (float)(_Float16)x; };
+    for (int t = 0; t < ntiles; t++)
+        for (int row = 0; row < 32; row++) {
+            const int i = t * 32 + row;
+            uint16_t ent[32];
+            memset(ent, 0, sizeof ent);
+            if (i < n && !big[i]) {
+                const double cx = (double)sph[i].c[0] * scale, cy = (double)sph[i].c[1] * scale, cz = (double)sph[i].c[2] * scale, rr = (double)sph[i].r * scale;
+                const float feat[9] = {(float)(cx * cx), (float)(cy * cy), (float)(cz * cz), (float)(cx * cy), (float)(cx * cz), (float)(cy * cz),
+                                       (float)cx, (float)cy, (float)cz};
+                for (int c = 0; c < 9; c++) {
+                    const uint16_t c1 = h16(feat[c]), c2 = h16(feat[c] - h16v(feat[c]));
+                    ent[3 * c] = c1; ent[3 * c + 1] = c1; ent[3 * c + 2] = c2;
+                }
+                ent[27] = ent[28] = h16(1.0f);
+                const float k = (float)(cx * cx + cy * cy + cz * cz - rr * rr);
+                ent[29] = h16(k); ent[30] = h16(k - h16v(k));
+            } else {
+                ent[29] = h16(60000.0f);             // never passes: the discriminant is -60000
+            }
+            for (int s2 = 0; s2 < 2; s2++)
+                for (int hh = 0; hh < 2; hh++)
+                    for (int j = 0; j < 8; j++)
+                        himg[(((size_t)t * 2 + s2) * 64 + hh * 32 + row) * 8 + j] = ent[16 * s2 + 8 * hh + j];
+        }
+
     // Rays as the renderer's waves hold them: the 64 lanes of a wave own adjacent pixels.  A wave's rays
     // are either camera rays through 64 neighbouring pixels, or bounce rays whose origins are the points
     // those camera rays would hit (close together) with independent random directions.
@@ -503,6 +666,7 @@ int main(int argc, char **argv)
 
     Params p;
     memset(&p, 0, sizeof p);
+    uint4 *d_himg; float *d_dump;
     Ray *d_rays; float *d_pairs; uint4 *d_aimg, *d_limg; unsigned *d_cnt, *d_sum; unsigned long long *d_total, *d_br;
     CHECK(hipMalloc(&d_rays, nrays * sizeof(Ray)));
     CHECK(hipMalloc(&d_pairs, pairs.size() * 4));
@@ -511,13 +675,17 @@ int main(int argc, char **argv)
     CHECK(hipMalloc(&d_sum, nrays * 4));
     CHECK(hipMalloc(&d_total, 8));
     CHECK(hipMalloc(&d_br, 8));
+    CHECK(hipMalloc(&d_himg, himg.size() * 2));
+    CHECK(hipMemcpy(d_himg, himg.data(), himg.size() * 2, hipMemcpyHostToDevice));
+    const int dump_waves = 256;
+    CHECK(hipMalloc(&d_dump, (size_t)dump_waves * 64 * ntiles * 32 * 4));
     CHECK(hipMalloc(&d_limg, limg.size() * 2));
     CHECK(hipMemcpy(d_limg, limg.data(), limg.size() * 2, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_rays, rays.data(), nrays * sizeof(Ray), hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_pairs, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_aimg, aimg.data(), aimg.size() * 2, hipMemcpyHostToDevice));
     p.rays = d_rays; p.nbatch = nbatch; p.pairs = d_pairs; p.aimg = d_aimg; p.n_pad = n_pad; p.ntiles = ntiles;
-    p.c_near = (float)c_near; p.out_count = d_cnt; p.out_sum = d_sum; p.out_total = d_total; p.out_branches = d_br; p.limg = d_limg; p.reps = 1;
+    p.c_near = (float)c_near; p.out_count = d_cnt; p.out_sum = d_sum; p.out_total = d_total; p.out_branches = d_br; p.limg = d_limg; p.reps = 1; p.himg = d_himg; p.scale = scale; p.dump = nullptr;
 
     const size_t lds_v = 4 * kSlots * 64 * 4;
     const size_t lds_m = (size_t)ntiles * 128 * 16 + 8 * 2 * kSlots * 64 * 4;
@@ -528,14 +696,55 @@ int main(int argc, char **argv)
     CHECK(hipFuncSetAttribute((const void *)scan_lifted<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
     CHECK(hipFuncSetAttribute((const void *)scan_lifted<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
     CHECK(hipFuncSetAttribute((const void *)scan_lifted<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l4));
+    const size_t lds_h = (size_t)ntiles * 128 * 16 + 8 * 2 * kLSlots * 64 * 2;
+    const size_t lds_h4 = (size_t)ntiles * 128 * 16 + 16 * 2 * kLSlots * 64 * 2;
+    CHECK(hipFuncSetAttribute((const void *)scan_f16<true, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
+    CHECK(hipFuncSetAttribute((const void *)scan_f16<true, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
+    CHECK(hipFuncSetAttribute((const void *)scan_f16<false, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
+    CHECK(hipFuncSetAttribute((const void *)scan_f16<false, 1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h4));
+
+    // ---- calibration: the accumulator against the discriminant in double precision, in units of (|O| + max|C|)^2
+    for (int which = 0; which < 2; which++) {
+        Params q = p; q.nbatch = 1; q.reps = 1; q.dump = d_dump; q.slack_scale = 0.0f;
+        CHECK(hipMemset(d_dump, 0, (size_t)dump_waves * 64 * ntiles * 32 * 4));
+        if (which == 0) hipLaunchKernelGGL((scan_lifted<true, 512>), dim3(dump_waves / 8), dim3(512), lds_l, 0, q);
+        else hipLaunchKernelGGL((scan_f16<true, 512, true>), dim3(dump_waves / 8), dim3(512), lds_h, 0, q);
+        CHECK(hipDeviceSynchronize());
+        std::vector<float> dump((size_t)dump_waves * 64 * ntiles * 32);
+        CHECK(hipMemcpy(dump.data(), d_dump, dump.size() * 4, hipMemcpyDeviceToHost));
+        // NOTE: with dump_waves < waves the ray index of wave w, lane l in batch 0 is w * 64 + l only for the
+        // launch geometry used here (nw = dump_waves)
+        double worst = 0, worst_abs = 0;
+        const double sc = which ? (double)scale : 1.0;
+        for (int rI = 0; rI < dump_waves * 64; rI++) {
+            const Ray &r = rays[rI];
+            const double on = sqrt((double)r.ox * r.ox + (double)r.oy * r.oy + (double)r.oz * r.oz) * sc;
+            const double S = on + c_near * sc;
+            for (int k = 0; k < n; k++) {
+                if (big[k]) continue;
+                double ocx = ((double)sph[k].c[0] - r.ox) * sc, ocy = ((double)sph[k].c[1] - r.oy) * sc, ocz = ((double)sph[k].c[2] - r.oz) * sc;
+                double hh = r.dx * ocx + r.dy * ocy + r.dz * ocz;
+                double dd = (double)r.dx * r.dx + (double)r.dy * r.dy + (double)r.dz * r.dz;      // d is unit to f32 rounding only
+                double disc = hh * hh - dd * (ocx * ocx + ocy * ocy + ocz * ocz) + (ocx * ocx + ocy * ocy + ocz * ocz) * (dd - 1.0)
+                              - ((ocx * ocx + ocy * ocy + ocz * ocz) - (double)sph[k].r * sph[k].r * sc * sc) + (ocx * ocx + ocy * ocy + ocz * ocz);
+                // the kernel's formula assumes |d| = 1: disc = h^2 - (|oc|^2 - r^2)
+                disc = hh * hh - (ocx * ocx + ocy * ocy + ocz * ocz - (double)sph[k].r * sph[k].r * sc * sc);
+                const double err = fabs((double)dump[(size_t)rI * (ntiles * 32) + k] - disc);
+                worst = std::max(worst, err / (S * S));
+                worst_abs = std::max(worst_abs, err);
+            }
+        }
+        printf("calibration %s: max |accumulator - discriminant| = %.3g = 2^%.2f x (|O| + max|C|)^2 over %d rays x %d spheres\n",
+               which ? "f16 x 2" : "bf16 x 3", worst_abs, log2(worst), dump_waves * 64, n);
+    }
 
     // ---- check: candidate sets
     const size_t ncheck = (size_t)waves_m * 64;           // first batch, at the matrix kernels' wave count
-    std::vector<unsigned> cnts[3], sums[3];
-    unsigned long long branches[3] = {0, 0, 0};
-    const char *names[3] = {"vector", "matrix", "lifted"};
-    const float slacks[3] = {1.9073486e-6f, 3.8146973e-6f, 3.8146973e-6f};     // 2^-19, 2^-18, 2^-18
-    for (int which = 0; which < 3; which++) {
+    std::vector<unsigned> cnts[4], sums[4];
+    unsigned long long branches[4] = {0, 0, 0, 0};
+    const char *names[4] = {"vector", "matrix", "lifted", "f16 x 2"};
+    const float slacks[4] = {1.9073486e-6f, 3.8146973e-6f, 3.8146973e-6f, 3.8146973e-6f};     // 2^-19, 2^-18, 2^-18, 2^-18
+    for (int which = 0; which < 4; which++) {
         cnts[which].resize(ncheck); sums[which].resize(ncheck);
         CHECK(hipMemset(d_cnt, 0xff, nrays * 4));
         CHECK(hipMemset(d_total, 0, 8));
@@ -543,13 +752,14 @@ int main(int argc, char **argv)
         Params q = p; q.nbatch = 1; q.reps = 1; q.slack_scale = slacks[which];
         if (which == 0) hipLaunchKernelGGL(scan_vector<true>, dim3(waves_m / 4), dim3(256), lds_v, 0, q);
         else if (which == 1) hipLaunchKernelGGL(scan_matrix<true>, dim3(waves_m / 8), dim3(512), lds_m, 0, q);
-        else hipLaunchKernelGGL((scan_lifted<true, 512>), dim3(waves_m / 8), dim3(512), lds_l, 0, q);
+        else if (which == 2) hipLaunchKernelGGL((scan_lifted<true, 512>), dim3(waves_m / 8), dim3(512), lds_l, 0, q);
+        else hipLaunchKernelGGL((scan_f16<true, 512, false>), dim3(waves_m / 8), dim3(512), lds_h, 0, q);
         CHECK(hipDeviceSynchronize());
         CHECK(hipMemcpy(cnts[which].data(), d_cnt, ncheck * 4, hipMemcpyDeviceToHost));
         CHECK(hipMemcpy(sums[which].data(), d_sum, ncheck * 4, hipMemcpyDeviceToHost));
         CHECK(hipMemcpy(&branches[which], d_br, 8, hipMemcpyDeviceToHost));
     }
-    size_t exact_total = 0, tot[3] = {0, 0, 0}, missing[3] = {0, 0, 0};
+    size_t exact_total = 0, tot[4] = {0, 0, 0, 0}, missing[4] = {0, 0, 0, 0};
     for (size_t i = 0; i < ncheck; i++) {
         const Ray &r = rays[i];
         unsigned ec = 0, es = 0;
@@ -562,13 +772,13 @@ int main(int argc, char **argv)
         }
         exact_total += ec;
         // a superset with equal size and equal index sum is the same set; a smaller set lost a sphere
-        for (int w = 0; w < 3; w++) {
+        for (int w = 0; w < 4; w++) {
             tot[w] += cnts[w][i];
             if (cnts[w][i] < ec || (cnts[w][i] == ec && sums[w][i] != es)) missing[w]++;
         }
     }
     printf("check over %zu rays: exact candidates %.3f per ray\n", ncheck, (double)exact_total / ncheck);
-    for (int w = 0; w < 3; w++)
+    for (int w = 0; w < 4; w++)
         printf("  %s filter: %.3f candidates per ray, rays with a lost sphere: %zu, append branches taken per wave scan: %.1f\n",
                names[w], (double)tot[w] / ncheck, missing[w], (double)branches[w] / (double)waves_m);
 
@@ -576,18 +786,21 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     const int reps = argc > 3 ? atoi(argv[3]) : 10;
-    const char *tnames[4] = {"vector", "matrix", "lifted 2 waves/SIMD", "lifted 4 waves/SIMD"};
-    for (int which = 0; which < 4; which++) {
+    const char *tnames[6] = {"vector", "matrix", "lifted 2 waves/SIMD", "lifted 4 waves/SIMD", "f16 x 2, 2 waves/SIMD", "f16 x 2, 4 waves/SIMD"};
+    for (int which = 0; which < 6; which++) {
         Params q = p;
-        q.slack_scale = slacks[which < 3 ? which : 2];
+        q.slack_scale = 3.8146973e-6f;
+        if (which == 0) q.slack_scale = 1.9073486e-6f;
         q.reps = reps;
-        const int waves = which == 0 ? waves_v : (which == 3 ? 2 * waves_m : waves_m);
+        const int waves = which == 0 ? waves_v : ((which == 3 || which == 5) ? 2 * waves_m : waves_m);
         for (int rep = 0; rep < 3; rep++) {
             CHECK(hipEventRecord(e0));
             if (which == 0) hipLaunchKernelGGL(scan_vector<false>, dim3(waves / 4), dim3(256), lds_v, 0, q);
             else if (which == 1) hipLaunchKernelGGL(scan_matrix<false>, dim3(waves / 8), dim3(512), lds_m, 0, q);
             else if (which == 2) hipLaunchKernelGGL((scan_lifted<false, 512>), dim3(waves / 8), dim3(512), lds_l, 0, q);
-            else hipLaunchKernelGGL((scan_lifted<false, 1024>), dim3(waves / 16), dim3(1024), lds_l4, 0, q);
+            else if (which == 3) hipLaunchKernelGGL((scan_lifted<false, 1024>), dim3(waves / 16), dim3(1024), lds_l4, 0, q);
+            else if (which == 4) hipLaunchKernelGGL((scan_f16<false, 512, false>), dim3(waves / 8), dim3(512), lds_h, 0, q);
+            else hipLaunchKernelGGL((scan_f16<false, 1024, false>), dim3(waves / 16), dim3(1024), lds_h4, 0, q);
             CHECK(hipEventRecord(e1));
             CHECK(hipDeviceSynchronize());
             float ms = 0;
