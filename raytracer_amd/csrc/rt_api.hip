@@ -76,6 +76,7 @@ struct Ctx {
     float c_near = 0.0f;
     DevBuf geom, matA, matB, pairs, aimg;
     int ntiles = 0;              // 32-sphere tiles of the matrix scan's image (0: the scene is too large for it)
+    float mat_scale = 1.0f;      // power-of-two scale of the matrix scan's frame
     // scratch
     DevBuf partial, counters, rgba, accum, hit, rows;
     // progressive accumulation (rt_render_progressive): running per-pixel sums and what they belong to
@@ -230,27 +231,19 @@ int scan_variant(const Ctx &g)
     return g.n > kMaxSpheresLds ? kScanVectorGlobal : kScanVectorLds;
 }
 
-// bf16 pieces of the matrix scan's sphere image: x = p[0] + p[1] + p[2] exactly (round to nearest even)
-uint16_t bf16_rne(float x)
+// f16 pieces of the matrix scan's sphere image: x = p[0] + p[1] + e, |e| <= 2^-24 |x| (round to nearest even)
+uint16_t f16_bits(float x)
 {
-    uint32_t u;
-    memcpy(&u, &x, 4);
-    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    const _Float16 h = (_Float16)x;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
 }
-float bf16_value(uint16_t b)
+void split2(float x, uint16_t p[2])
 {
-    const uint32_t u = (uint32_t)b << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
-void split3(float x, uint16_t p[3])
-{
-    p[0] = bf16_rne(x);
-    const float r1 = x - bf16_value(p[0]);
-    p[1] = bf16_rne(r1);
-    const float r2 = r1 - bf16_value(p[1]);
-    p[2] = bf16_rne(r2);
+    const _Float16 h = (_Float16)x;
+    p[0] = f16_bits(x);
+    p[1] = f16_bits(x - (float)h);
 }
 
 struct Call {
@@ -378,6 +371,7 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             tp.pairs = (const float *)g.pairs.p;
             tp.aimg = (const uint4 *)g.aimg.p; tp.ntiles = g.ntiles;
             tp.mat_slots = mat_slots(g.n_pad, g.ntiles);
+            tp.mat_scale = g.mat_scale; tp.mat_c_near = g.c_near * g.mat_scale;
             tp.n = g.n; tp.n_pad = g.n_pad;
             tp.nbig = g.nbig; memcpy(tp.big, g.big, sizeof tp.big); tp.c_near = g.c_near;
             // one ray over all spheres costs about 9 vector instructions per sphere pair in the scan (for
@@ -779,45 +773,52 @@ static int set_world_impl(const rt_sphere *spheres, size_t count)
             q[0] = 0.0f; q[2] = 0.0f; q[4] = 0.0f; q[6] = inf;       // never passes the filter
         }
     }
-    // Matrix scan: per 32-sphere tile the MFMA A fragments of the sphere features (rt_device.h).  K entries
-    // of a sphere: feature f of (cx^2, cy^2, cz^2, cx cy, cx cz, cy cz, cx, cy, cz) at 6 f .. 6 f + 5 as
-    // (c1, c1, c2, c1, c3, c2); 54-56: 1, 1, 1; 57-59: the pieces of k = |C|^2 - r^2; 60-63: 0.
-    // Rows beyond the scene and the big spheres hold k = 3e38 only: their discriminant is -3e38.
+    // Matrix scan: per 32-sphere tile the MFMA A fragments of the sphere features (rt_device.h), in a
+    // frame scaled by a power of two that puts every filtered sphere within 120 of the origin (f16 range:
+    // products of coordinates stay below 65504).  K entries of a sphere: feature f of (cx^2, cy^2, cz^2,
+    // cx cy, cx cz, cy cz, cx, cy, cz) at 3 f .. 3 f + 2 as (c1, c1, c2); 27, 28: 1, 1; 29, 30: the pieces
+    // of k = |C|^2 - r^2; 31: 0.  Rows beyond the scene and the big spheres hold k = 65504 only: the ray's
+    // constant is capped at 60000 (rt_trace_impl.h), so their accumulator stays below -5000.
     int ntiles = n <= kMaxSpheresMatrix ? std::max(1, (n + kTileSpheres - 1) / kTileSpheres) : 0;
     if (ntiles > 0 && mat_slots(n_pad, ntiles) < kMatSlotsMin) ntiles = 0;      // no room for the queues: vector scan
-    std::vector<uint16_t> aimg((size_t)ntiles * 4 * 64 * 8, 0);
+    double reach = 0.0;
+    for (int i = 0; i < n; i++) if (!is_big[i]) reach = std::max(reach, extent[i]);
+    float mat_scale = 1.0f;
+    if (reach > 0.0) mat_scale = (float)std::exp2(std::min(100.0, std::max(-100.0, std::floor(std::log2(120.0 / reach)))));
+    std::vector<uint16_t> aimg((size_t)ntiles * 2 * 64 * 8, 0);
     for (int t = 0; t < ntiles; t++)
         for (int row = 0; row < kTileSpheres; row++) {
             const int i = t * kTileSpheres + row;
-            uint16_t ent[64];
+            uint16_t ent[32];
             memset(ent, 0, sizeof ent);
             if (i < n && !is_big[i]) {
-                const double cx = spheres[i].center.x, cy = spheres[i].center.y, cz = spheres[i].center.z;
+                const double cx = (double)spheres[i].center.x * mat_scale, cy = (double)spheres[i].center.y * mat_scale,
+                             cz = (double)spheres[i].center.z * mat_scale, rr = (double)spheres[i].radius * mat_scale;
                 const float feat[9] = {(float)(cx * cx), (float)(cy * cy), (float)(cz * cz), (float)(cx * cy), (float)(cx * cz),
                                        (float)(cy * cz), (float)cx, (float)cy, (float)cz};
                 for (int f = 0; f < 9; f++) {
-                    uint16_t pc[3];
-                    split3(feat[f], pc);
-                    const uint16_t six[6] = {pc[0], pc[0], pc[1], pc[0], pc[2], pc[1]};
-                    for (int e = 0; e < 6; e++) ent[6 * f + e] = six[e];
+                    uint16_t pc[2];
+                    split2(feat[f], pc);
+                    ent[3 * f] = pc[0]; ent[3 * f + 1] = pc[0]; ent[3 * f + 2] = pc[1];
                 }
-                ent[54] = ent[55] = ent[56] = bf16_rne(1.0f);
-                uint16_t kp[3];
-                split3((float)(cx * cx + cy * cy + cz * cz - (double)spheres[i].radius * spheres[i].radius), kp);
-                ent[57] = kp[0]; ent[58] = kp[1]; ent[59] = kp[2];
+                ent[27] = ent[28] = f16_bits(1.0f);
+                uint16_t kp[2];
+                split2((float)(cx * cx + cy * cy + cz * cz - rr * rr), kp);
+                ent[29] = kp[0]; ent[30] = kp[1];
             } else {
-                ent[57] = bf16_rne(3.0e38f);
+                ent[29] = f16_bits(65504.0f);
             }
-            for (int s2 = 0; s2 < 4; s2++)
+            for (int s2 = 0; s2 < 2; s2++)
                 for (int hh = 0; hh < 2; hh++)
                     for (int e = 0; e < 8; e++)
-                        aimg[(((size_t)t * 4 + s2) * 64 + hh * 32 + row) * 8 + e] = ent[16 * s2 + 8 * hh + e];
+                        aimg[(((size_t)t * 2 + s2) * 64 + hh * 32 + row) * 8 + e] = ent[16 * s2 + 8 * hh + e];
         }
     for (int k = 0; k < g_nctx; k++) {
         Ctx &g = g_ctx[k];
         HIP_TRY(hipSetDevice(g.device));
         HIP_TRY(hipStreamSynchronize(g.stream));
         g.ntiles = ntiles;
+        g.mat_scale = mat_scale;
         if (ntiles > 0) {
             HIP_TRY(g.aimg.reserve(aimg.size() * sizeof(uint16_t)));
             HIP_TRY(hipMemcpy(g.aimg.p, aimg.data(), aimg.size() * sizeof(uint16_t), hipMemcpyHostToDevice));

@@ -35,20 +35,22 @@ constexpr int kQueueSlotsFast = 14;        // candidate-queue slots per lane
 constexpr int kQueueSlotsStrict = 16;
 constexpr int queue_lds_bytes(int block_threads, int slots) { return (block_threads / 64) * slots * 64 * 4; }   // waves x slots x 64 lanes x u32
 // The sphere scan comes in three variants.
-//   kScanMatrix       up to kMaxSpheresMatrix spheres: the conservative filter runs on the matrix cores.
-//                     The discriminant of (ray, sphere) with a unit direction d, g = d.O, w = 2 (O - g d) is
+//   kScanMatrix       scenes whose matrix image fits the LDS: the conservative filter runs on the matrix
+//                     cores.  The discriminant of (ray, sphere) with a unit direction d, g = d.O,
+//                     w = 2 (O - g d) is
 //                         disc = sum_ij (d_i d_j)(c_i c_j) + w.C + (g^2 - |O|^2) - (|C|^2 - r^2),
-//                     one inner product of ten ray features with ten sphere features.  Each f32 feature is
-//                     split exactly into three bf16 pieces x = x1 + x2 + x3 and the six piece products of
-//                     weight >= 2^-16 are summed by v_mfma_f32_32x32x16_bf16 in f32 (K = 9 x 6 + 3 + 3 = 60
-//                     of 64): 32 spheres x 32 rays per 4 instructions; the vector ALU only compares the
-//                     accumulators with zero.  aimg[tile][s][lane] holds the sphere side as MFMA A
-//                     fragments (lane l: sphere 32 tile + (l & 31), K entries 16 s + 8 (l >> 5) ..+7).
+//                     one inner product of ten ray features with ten sphere features.  In a frame scaled
+//                     by a power of two (spheres within 120 of the origin) each f32 feature is split into
+//                     two f16 pieces x = x1 + x2 and the products x1 y1 + x1 y2 + x2 y1 are summed by
+//                     v_mfma_f32_32x32x16_f16 in f32 (K = 9 x 3 + 2 + 2 = 31 of 32): 32 spheres x 32 rays
+//                     per 2 instructions; the vector ALU only compares the accumulators with zero.
+//                     aimg[tile][s][lane] holds the sphere side as MFMA A fragments (lane l: sphere
+//                     32 tile + (l & 31), K entries 16 s + 8 (l >> 5) ..+7).
 //   kScanVectorLds    packed-FP32 vector scan, per-sphere records in LDS (selectable for comparison)
 //   kScanVectorGlobal packed-FP32 vector scan, per-sphere records from global memory (larger scenes)
 enum { kScanVectorLds = 0, kScanVectorGlobal = 1, kScanMatrix = 2, kScanVariants = 3 };
 constexpr int kTileSpheres = 32;
-constexpr int kMaxTilesMatrix = 18;        // sphere image 4 KB per tile: 72 KB of LDS next to the queues
+constexpr int kMaxTilesMatrix = 35;        // sphere image 2 KB per tile (+ 0.5 KB of geometry): what leaves room for the queues
 constexpr int kMaxSpheresMatrix = kMaxTilesMatrix * kTileSpheres;
 constexpr int kMatBlockThreads = RT_MAT_THREADS;   // one workgroup per CU: 4 waves per SIMD at 128 VGPRs
 constexpr int kLdsBytes = 160 * 1024;
@@ -57,7 +59,7 @@ constexpr int kLdsBytes = 160 * 1024;
 constexpr int kMatSlotsMin = 18, kMatSlotsMax = 32;
 inline int mat_slots(int n_pad, int ntiles)
 {
-    const long room = (long)kLdsBytes - (long)ntiles * 256 * 16 - (long)n_pad * 16;
+    const long room = (long)kLdsBytes - (long)ntiles * 128 * 16 - (long)n_pad * 16;
     const long s = room / ((kMatBlockThreads / 64) * 2 * 64 * 2);
     return (int)(s > kMatSlotsMax ? kMatSlotsMax : s);
 }
@@ -76,7 +78,9 @@ struct TraceParams {
     const float4 *matA;                    // [n]
     const float4 *matB;                    // [n]
     const float *pairs;                    // [n_pad / 2][8]
-    const uint4 *aimg;                     // [ntiles][4][64] bf16 fragments of the matrix scan, or nullptr
+    const uint4 *aimg;                     // [ntiles][2][64] f16 fragments of the matrix scan, or nullptr
+    float mat_scale;                       // power-of-two scale of the matrix scan's frame
+    float mat_c_near;                      // max |C| over the filtered spheres, in that frame
     int ntiles;
     int mat_slots;                         // queue slots per lane and ray half (matrix scan)
     int n, n_pad;
@@ -147,7 +151,7 @@ int trace_blocks_per_cu_fast(LaunchCache &c, int variant, size_t lds_bytes);
 inline size_t trace_lds_bytes(int variant, bool strict, int n_pad, int ntiles)
 {
     if (variant == kScanMatrix)
-        return (size_t)ntiles * 256 * sizeof(uint4) + (size_t)n_pad * sizeof(float4) +
+        return (size_t)ntiles * 128 * sizeof(uint4) + (size_t)n_pad * sizeof(float4) +
                (size_t)(kMatBlockThreads / 64) * 2 * mat_slots(n_pad, ntiles) * 64 * sizeof(uint16_t);
     return (variant == kScanVectorGlobal ? 0 : (size_t)n_pad * sizeof(float4)) +
            (size_t)queue_lds_bytes(kBlockThreads, strict ? kQueueSlotsStrict : kQueueSlotsFast);

@@ -355,29 +355,18 @@ __device__ __forceinline__ void scan_spheres(const TraceParams &p, const float4 
 
 // ---- the filter on the matrix cores ---------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-// (bf16(lo), bf16(hi)) in one register, round to nearest even (v_cvt_pk_bf16_f32)
-__device__ __forceinline__ uint32_t bf16_pair(float lo, float hi)
+__device__ __forceinline__ uint32_t pack_f16(_Float16 lo, _Float16 hi)
 {
-    const f2 v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    const f16x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
 
-// x = x1 + x2 + x3 exactly, three bf16 pieces; returns the packed pairs (x1, x2) and (x1, x3)
-__device__ __forceinline__ void split3(float x, uint32_t &p12, uint32_t &p13)
+__device__ __forceinline__ f16x8 as_frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
 {
-    const float x1 = __uint_as_float(bf16_pair(x, x) << 16);
-    const float r1 = x - x1;
-    p12 = bf16_pair(x, r1);
-    const float r2 = r1 - __uint_as_float(p12 & 0xffff0000u);
-    p13 = bf16_pair(x, r2);
-}
-
-__device__ __forceinline__ bf16x8 as_frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
-{
-    return __builtin_bit_cast(bf16x8, make_uint4(a, b, c, d));
+    return __builtin_bit_cast(f16x8, make_uint4(a, b, c, d));
 }
 
 // Exact test of the queued candidates of every lane's OWN ray.  An accumulator column is a ray and
@@ -399,7 +388,9 @@ __device__ __forceinline__ void drain_matrix(const float4 *s_geom, const uint16_
         dg.drain_iters++; dg.drain_lanes += (uint32_t)__popcll(__ballot(j < total));
 #endif
         if (j < total) {
-            const int i = j < mine ? (int)qa[j * 64 + lane] : (int)qa[(j - mine) * 64 + (lane ^ 32)];
+            // an entry holds the tile's first sphere plus the accumulator's row offset; the half of the lane
+            // that queued it adds 4 (its rows are (i & 3) + 8 (i >> 2) + 4 (lane >> 5))
+            const int i = j < mine ? (int)qa[j * 64 + lane] + 4 * h : (int)qa[(j - mine) * 64 + (lane ^ 32)] + 4 - 4 * h;
             exact_test(s_geom, i, q);
         }
     }
@@ -427,7 +418,7 @@ __device__ __forceinline__ void queue_passes(const f32x16 &acc, int first, int l
 #endif
         // the group maxima say where to look: five groups of three rows and the last row
         auto put = [&](int i) {
-            if (acc[i] >= 0.0f) {                            // row (i & 3) + 8 (i >> 2) + 4 (lane >> 5) of the tile
+            if (acc[i] >= 0.0f) {                            // row (i & 3) + 8 (i >> 2) (+ 4 (lane >> 5), added by the drain)
 #ifdef RT_DIAG
                 dg.passes++;
 #endif
@@ -445,8 +436,16 @@ __device__ __forceinline__ void queue_passes(const f32x16 &acc, int first, int l
 }
 
 // hit() (Main.c:688-713) as matrix filter + exact test; u is the unit direction.
+//
+// Error budget of the filter, in the scaled frame (S = |O'| + max|C'|).  A feature is x = x1 + x2 + e with
+// |e| <= 2^-24 |x| (two f16 pieces, round to nearest); the product x2 y2 is dropped (<= 2^-24 |x||y|); the
+// features themselves carry f32 roundings (a few 2^-24 S^2 in all).  The MFMA sums the 16 exact products of
+// an instruction and its C input in a window of 24 bits below the largest of them and truncates what lies
+// below (measured: tools/mfma_prec): at most 2^-23 of the largest term per term, 32 terms, every term
+// <= S^2, hence <= 2^-18 S^2.  slack = 2^-16 S^2 (+ 0.01 for f16 subnormal pieces) is four times that bound
+// and also covers the rounding of the exact test that decides afterwards.
 __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const float4 *s_geom, const uint4 *s_aimg, uint16_t *queue,
-                                                    int lane, float ux, float uy, float uz, float slack_scale, Probe &q RT_DIAG_ARG)
+                                                    int lane, float ux, float uy, float uz, Probe &q RT_DIAG_ARG)
 {
 #ifdef RT_DIAG
     const unsigned long long tb0 = RT_STAMP();
@@ -455,77 +454,97 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
 #ifdef RT_DIAG
     dg.t_big += RT_STAMP() - tb0;
 #endif
-    // ray features: (d_i d_j), w = 2 (O - g d), g^2 - |O|^2 + slack; slack bounds the rounding of the
-    // features, of the dropped piece products, of the accumulation and of the exact test it stands before
-    const float ox = q.ox, oy = q.oy, oz = q.oz;
+    // ray features in the frame scaled by p.mat_scale (a power of two)
+    const float ox = q.ox * p.mat_scale, oy = q.oy * p.mat_scale, oz = q.oz * p.mat_scale;
     const float oo = fmaf(oz, oz, fmaf(oy, oy, ox * ox));
-    const float reach = __builtin_amdgcn_sqrtf(oo) * 1.0000005f + p.c_near;
-    const float slack = fmaf(reach * reach, slack_scale, 1e-30f);
+    const float reach = __builtin_amdgcn_sqrtf(oo) * 1.0000005f + p.mat_c_near;
+    const float slack = fmaf(reach * reach, 1.52587890625e-5f, 0.01f);            // 2^-16
+    // The discriminant does not change when the origin slides along the ray: take the point of the line
+    // nearest to the frame's origin, P = O' - (u . O') u.  Then u . P = 0 up to rounding (covered by the
+    // slack: |dP| <= 7 * 2^-24 |O'|, which moves the discriminant by <= 2^-20 S^2), the features are
+    // (d_i d_j), 2 P and slack - |P|^2, and |P| is bounded by what f16 holds whenever the ray can meet a
+    // filtered sphere at all (they lie within 120 of the origin): a line farther than 248 away gets
+    // features that pass nothing.
     const float g = fmaf(uz, oz, fmaf(uy, oy, ux * ox));
-    float feat[9];
+    const float px = fmaf(-g, ux, ox), py = fmaf(-g, uy, oy), pz = fmaf(-g, uz, oz);
+    const float pp = fmaf(pz, pz, fmaf(py, py, px * px));
+    const bool apart = !(pp <= 61504.0f);                                        // 248^2; also catches NaN
+    float feat[10];
     feat[0] = ux * ux; feat[1] = uy * uy; feat[2] = uz * uz;
     feat[3] = 2.0f * ux * uy; feat[4] = 2.0f * ux * uz; feat[5] = 2.0f * uy * uz;
-    feat[6] = 2.0f * fmaf(-g, ux, ox); feat[7] = 2.0f * fmaf(-g, uy, oy); feat[8] = 2.0f * fmaf(-g, uz, oz);
-    const float cst = fmaf(g, g, slack - oo);
-    // K entries of the lane's own ray, two per register: feature f at entries 6 f .. 6 f + 5 as
-    // (x1, x2, x1, x3, x1, x2) against the sphere side's (c1, c1, c2, c1, c3, c2); then the constant
-    // against 1, 1, 1 and -1, -1, -1 against the pieces of k
-    uint32_t R[32];
+    feat[6] = 2.0f * px; feat[7] = 2.0f * py; feat[8] = 2.0f * pz;
+    feat[9] = fminf(slack - pp, 60000.0f);                                       // a slack beyond f16: everything passes
+    if (apart) {
 #pragma unroll
-    for (int f = 0; f < 9; f++) {
-        split3(feat[f], R[3 * f], R[3 * f + 1]);
-        R[3 * f + 2] = R[3 * f];
+        for (int f = 0; f < 9; f++) feat[f] = 0.0f;
+        feat[9] = oo < 1e15f ? -1.0f : 60000.0f;         // so far out that P itself is uncertain: everything passes
     }
-    {
-        uint32_t c12, c13;
-        split3(cst, c12, c13);
-        R[27] = c12;
-        R[28] = (c13 >> 16) | 0xbf800000u;           // (c3, -1)
-        R[29] = 0xbf80bf80u;                         // (-1, -1)
-        R[30] = 0u; R[31] = 0u;
+    _Float16 x1[10], x2[10];
+#pragma unroll
+    for (int f = 0; f < 10; f++) {
+        // The feature must be an f32 VALUE before it is split.  Left visible, the multiply that produced it is
+        // fused with the conversion into one mixed-precision FMA (one rounding, product -> f16) for the use in the
+        // subtraction, while the packed copy of x1 converts the rounded f32 (two roundings): the two x1 then
+        // differ by an f16 ulp now and then, and x1 + x2 misses the feature by 2^-11 of it.
+        asm volatile("" : "+v"(feat[f]));
+        x1[f] = (_Float16)feat[f];
+        x2[f] = (_Float16)(feat[f] - (float)x1[f]);
     }
+    // K entries of the lane's own ray, two per register.  Feature f (f < 9) at entries 3 f .. 3 f + 2 as
+    // (x1, x2, x1) against the sphere side's (c1, c1, c2); entries 27, 28: the constant's pieces against
+    // 1, 1; entries 29, 30: -1, -1 against the pieces of k; entry 31: 0.
+    const _Float16 m1 = (_Float16)-1.0f, z0 = (_Float16)0.0f;
+    uint32_t R[16];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {                     // features 2 k and 2 k + 1 fill three registers
+        R[3 * k] = pack_f16(x1[2 * k], x2[2 * k]);
+        R[3 * k + 1] = pack_f16(x1[2 * k], x1[2 * k + 1]);
+        R[3 * k + 2] = pack_f16(x2[2 * k + 1], x1[2 * k + 1]);
+    }
+    R[12] = pack_f16(x1[8], x2[8]);
+    R[13] = pack_f16(x1[8], x1[9]);
+    R[14] = pack_f16(x2[9], m1);
+    R[15] = pack_f16(m1, z0);
     // B fragments: half H holds rays 32 H .. 32 H + 31 in its columns; lanes 0-31 supply K entries 0-7
     // of an instruction, lanes 32-63 entries 8-15, of the COLUMN's ray.  One half-swap per register
     // pair gives both halves' fragments.
-    uint32_t B[2][4][4];
+    uint32_t B[2][2][4];
 #pragma unroll
-    for (int s2 = 0; s2 < 4; s2++)
+    for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
         for (int v = 0; v < 4; v++) {
             const auto sw = __builtin_amdgcn_permlane32_swap(R[8 * s2 + v], R[8 * s2 + 4 + v], false, false);
             B[0][s2][v] = sw[0]; B[1][s2][v] = sw[1];
         }
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    auto chain = [&](const bf16x8 (&a)[4], int H) {
-        f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], as_frag(B[H][0][0], B[H][0][1], B[H][0][2], B[H][0][3]), zero, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], as_frag(B[H][1][0], B[H][1][1], B[H][1][2], B[H][1][3]), d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], as_frag(B[H][2][0], B[H][2][1], B[H][2][2], B[H][2][3]), d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[3], as_frag(B[H][3][0], B[H][3][1], B[H][3][2], B[H][3][3]), d, 0, 0, 0);
-        return d;
-    };
-    const int row4 = 4 * (lane >> 5);
     const int slots = p.mat_slots;
     int cnt0 = 0, cnt1 = 0;
-    bf16x8 a[4], an[4];
+    f16x8 a[2], an[2];
 #pragma unroll
-    for (int s2 = 0; s2 < 4; s2++) a[s2] = __builtin_bit_cast(bf16x8, s_aimg[s2 * 64 + lane]);
-    f32x16 acc0 = chain(a, 0);
-    // software pipeline: the MFMAs of the next half are issued before the compares of the current one
+    for (int s2 = 0; s2 < 2; s2++) a[s2] = __builtin_bit_cast(f16x8, s_aimg[s2 * 64 + lane]);
+    // Per tile: read the NEXT tile's fragments, issue this tile's four MFMAs (the two halves interleaved, so
+    // that no instruction waits for the one before it), compare.  The order matters for correctness, not only
+    // for speed: a matrix instruction reads its A and B registers when it starts, which under four waves per
+    // SIMD can be long after it was issued, and nothing stops an LDS read or a VALU result from landing in
+    // those registers in between.  So the fragment reads are issued BEFORE the MFMAs, into registers of their
+    // own, and every register an MFMA reads stays untouched until its accumulators have been read (which
+    // waits for the instruction to finish): no MFMA is in flight when the loop or the scan ends.
     for (int t = 0; t < p.ntiles; t++) {
-        f32x16 acc1 = chain(a, 1);
         const int tn = t + 1 < p.ntiles ? t + 1 : t;
 #pragma unroll
-        for (int s2 = 0; s2 < 4; s2++) an[s2] = __builtin_bit_cast(bf16x8, s_aimg[(tn * 4 + s2) * 64 + lane]);
+        for (int s2 = 0; s2 < 2; s2++) an[s2] = __builtin_bit_cast(f16x8, s_aimg[(tn * 2 + s2) * 64 + lane]);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], as_frag(B[0][0][0], B[0][0][1], B[0][0][2], B[0][0][3]), zero, 0, 0, 0);
+        f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], as_frag(B[1][0][0], B[1][0][1], B[1][0][2], B[1][0][3]), zero, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], as_frag(B[0][1][0], B[0][1][1], B[0][1][2], B[0][1][3]), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], as_frag(B[1][1][0], B[1][1][1], B[1][1][2], B[1][1][3]), acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         bool appended = false;
-        __builtin_amdgcn_sched_barrier(0);
-        queue_passes(acc0, t * kTileSpheres + row4, lane, queue, cnt0, appended RT_DIAG_PASS);
-        __builtin_amdgcn_sched_barrier(0);
-        acc0 = chain(an, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        queue_passes(acc1, t * kTileSpheres + row4, lane, queue + slots * 64, cnt1, appended RT_DIAG_PASS);
+        queue_passes(acc0, t * kTileSpheres, lane, queue, cnt0, appended RT_DIAG_PASS);
+        queue_passes(acc1, t * kTileSpheres, lane, queue + slots * 64, cnt1, appended RT_DIAG_PASS);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s2 = 0; s2 < 4; s2++) a[s2] = an[s2];
+        for (int s2 = 0; s2 < 2; s2++) a[s2] = an[s2];
         // a half tile adds at most 16 entries to a queue
         if (appended && __ballot(cnt0 > slots - 16 || cnt1 > slots - 16) != 0ULL) {
             drain_matrix(s_geom, queue, slots, cnt0, cnt1, lane, q RT_DIAG_PASS);
@@ -652,9 +671,9 @@ __global__ __launch_bounds__(VARIANT == kScanMatrix ? kMatBlockThreads : kBlockT
     const uint4 *s_aimg = nullptr;
     uint16_t *queue16 = nullptr;
     if (VARIANT == kScanMatrix) {
-        uint4 *img = reinterpret_cast<uint4 *>(lds);                       // [ntiles][4][64]
-        for (int i = threadIdx.x; i < p.ntiles * 256; i += blockDim.x) img[i] = p.aimg[i];
-        float4 *gm = lds + p.ntiles * 256;                                 // [n_pad]
+        uint4 *img = reinterpret_cast<uint4 *>(lds);                       // [ntiles][2][64]
+        for (int i = threadIdx.x; i < p.ntiles * 128; i += blockDim.x) img[i] = p.aimg[i];
+        float4 *gm = lds + p.ntiles * 128;                                 // [n_pad]
         for (int i = threadIdx.x; i < p.n_pad; i += blockDim.x) gm[i] = p.geom[i];
         s_aimg = img; s_geom = gm;
         s_matA = p.matA; s_matB = p.matB;
@@ -788,7 +807,7 @@ __global__ __launch_bounds__(VARIANT == kScanMatrix ? kMatBlockThreads : kBlockT
             const float inv = (q.a > 0.0f) ? __builtin_amdgcn_rsqf(q.a) : 0.0f;
             const unsigned long long live = __ballot(active);
             if (__popcll(live) <= p.coop_max) shared_ray_hit(p, s_geom, lane, live, q);
-            else if (VARIANT == kScanMatrix) scan_spheres_matrix(p, s_geom, s_aimg, queue16, lane, q.dx * inv, q.dy * inv, q.dz * inv, 7.6293945e-6f, q RT_DIAG_PASS);
+            else if (VARIANT == kScanMatrix) scan_spheres_matrix(p, s_geom, s_aimg, queue16, lane, q.dx * inv, q.dy * inv, q.dz * inv, q RT_DIAG_PASS);
             else scan_spheres(p, s_geom, queue, lane, q.dx * inv, q.dy * inv, q.dz * inv, 7.6293945e-6f, q RT_DIAG_PASS);
             if (!(q.a > 0.0f)) {
                 // a zero or NaN direction gives the filter nothing to work with: test everything
@@ -799,7 +818,7 @@ __global__ __launch_bounds__(VARIANT == kScanMatrix ? kMatBlockThreads : kBlockT
 #else
         const unsigned long long live = __ballot(active);
         if (__popcll(live) <= p.coop_max) shared_ray_hit(p, s_geom, lane, live, q);
-        else if (VARIANT == kScanMatrix) scan_spheres_matrix(p, s_geom, s_aimg, queue16, lane, q.dx, q.dy, q.dz, 3.8146973e-6f, q RT_DIAG_PASS);   // 2^-18
+        else if (VARIANT == kScanMatrix) scan_spheres_matrix(p, s_geom, s_aimg, queue16, lane, q.dx, q.dy, q.dz, q RT_DIAG_PASS);
         else scan_spheres(p, s_geom, queue, lane, q.dx, q.dy, q.dz, 1.9073486e-6f, q RT_DIAG_PASS);   // 2^-19
 #ifdef RT_DIAG
         if (__popcll(live) <= p.coop_max) dg.shared_rays += (uint32_t)__popcll(live); else dg.scan_lanes += (uint32_t)__popcll(live);
@@ -821,7 +840,14 @@ __global__ __launch_bounds__(VARIANT == kScanMatrix ? kMatBlockThreads : kBlockT
 #if !RT_STRICT
             if (L.zero_dir) all.hit = -1;
 #endif
-            if (active && (all.hit != q.hit || (all.hit >= 0 && all.closest != q.closest))) dg.lost_hits++;
+            if (active && (all.hit != q.hit || (all.hit >= 0 && all.closest != q.closest))) {
+                dg.lost_hits++;
+                if (dg.lost_hits <= 2)
+                    printf("lost hit: o %.9g %.9g %.9g d %.9g %.9g %.9g: all-spheres test %d at %.9g, scan %d at %.9g; lane %d block %d live %d bounce %d scans %u drains %u\n",
+                           (double)q.ox, (double)q.oy, (double)q.oz, (double)q.dx, (double)q.dy, (double)q.dz,
+                           all.hit, (double)all.closest, q.hit, (double)q.closest, lane, (int)blockIdx.x,
+                           (int)__popcll(__ballot(active)), L.bounce, dg.scans, dg.drain_iters);
+            }
         }
 #endif
         const float closest = q.closest;

@@ -417,6 +417,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void scan_f16(const Params 
         _Float16 x1[10], x2[10];
 #pragma unroll
         for (int f = 0; f < 10; f++) {
+            asm volatile("" : "+v"(feat[f]));      // no fused multiply-convert: x1 must be the rounding of the f32 feature
             x1[f] = (_Float16)feat[f];
             x2[f] = (_Float16)(feat[f] - (float)x1[f]);
         }
@@ -703,6 +704,16 @@ int main(int argc, char **argv)
     CHECK(hipFuncSetAttribute((const void *)scan_f16<false, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
     CHECK(hipFuncSetAttribute((const void *)scan_f16<false, 1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h4));
 
+    // optional: argv[4] = "ox,oy,oz,dx,dy,dz" replaces ray 0 (direction is normalised here) and its accumulators are printed
+    const bool probe = argc > 4;
+    if (probe) {
+        float v[6];
+        if (sscanf(argv[4], "%f,%f,%f,%f,%f,%f", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) != 6) { fprintf(stderr, "bad ray\n"); return 2; }
+        const float a = v[3] * v[3] + v[4] * v[4] + v[5] * v[5];
+        const float inv = 1.0f / sqrtf(a);
+        for (int l = 0; l < 64; l++) rays[l] = Ray{v[0], v[1], v[2], v[3] * inv, v[4] * inv, v[5] * inv};
+        CHECK(hipMemcpy(d_rays, rays.data(), 64 * sizeof(Ray), hipMemcpyHostToDevice));
+    }
     // ---- calibration: the accumulator against the discriminant in double precision, in units of (|O| + max|C|)^2
     for (int which = 0; which < 2; which++) {
         Params q = p; q.nbatch = 1; q.reps = 1; q.dump = d_dump; q.slack_scale = 0.0f;
@@ -714,7 +725,8 @@ int main(int argc, char **argv)
         CHECK(hipMemcpy(dump.data(), d_dump, dump.size() * 4, hipMemcpyDeviceToHost));
         // NOTE: with dump_waves < waves the ray index of wave w, lane l in batch 0 is w * 64 + l only for the
         // launch geometry used here (nw = dump_waves)
-        double worst = 0, worst_abs = 0;
+        double worst = 0, worst_abs = 0, worst_acc = 0, worst_disc = 0;
+        int worst_r = 0, worst_k = 0;
         const double sc = which ? (double)scale : 1.0;
         for (int rI = 0; rI < dump_waves * 64; rI++) {
             const Ray &r = rays[rI];
@@ -730,12 +742,17 @@ int main(int argc, char **argv)
                 // the kernel's formula assumes |d| = 1: disc = h^2 - (|oc|^2 - r^2)
                 disc = hh * hh - (ocx * ocx + ocy * ocy + ocz * ocz - (double)sph[k].r * sph[k].r * sc * sc);
                 const double err = fabs((double)dump[(size_t)rI * (ntiles * 32) + k] - disc);
+                if (probe && which == 1 && (rI == 0 || rI == 37) && (k % 16 == 2 || err > 0.05)) printf("  ray %d sphere %d: accumulator %.6f discriminant %.6f\n", rI, k, dump[(size_t)rI * (ntiles * 32) + k], disc);
                 worst = std::max(worst, err / (S * S));
+                if (err > worst_abs) { worst_r = rI; worst_k = k; worst_acc = dump[(size_t)rI * (ntiles * 32) + k]; worst_disc = disc; }
                 worst_abs = std::max(worst_abs, err);
             }
         }
         printf("calibration %s: max |accumulator - discriminant| = %.3g = 2^%.2f x (|O| + max|C|)^2 over %d rays x %d spheres\n",
                which ? "f16 x 2" : "bf16 x 3", worst_abs, log2(worst), dump_waves * 64, n);
+        printf("  worst: ray %d o %.9g %.9g %.9g d %.9g %.9g %.9g sphere %d c %.9g %.9g %.9g r %.9g accumulator %.6f discriminant %.6f\n", worst_r,
+               rays[worst_r].ox, rays[worst_r].oy, rays[worst_r].oz, rays[worst_r].dx, rays[worst_r].dy, rays[worst_r].dz, worst_k,
+               sph[worst_k].c[0], sph[worst_k].c[1], sph[worst_k].c[2], sph[worst_k].r, worst_acc, worst_disc);
     }
 
     // ---- check: candidate sets
@@ -785,6 +802,7 @@ int main(int argc, char **argv)
     // ---- timing
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    if (probe) return 0;
     const int reps = argc > 3 ? atoi(argv[3]) : 10;
     const char *tnames[6] = {"vector", "matrix", "lifted 2 waves/SIMD", "lifted 4 waves/SIMD", "f16 x 2, 2 waves/SIMD", "f16 x 2, 4 waves/SIMD"};
     for (int which = 0; which < 6; which++) {
