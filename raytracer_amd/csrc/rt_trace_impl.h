@@ -475,9 +475,9 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
     feat[6] = 2.0f * px; feat[7] = 2.0f * py; feat[8] = 2.0f * pz;
     feat[9] = fminf(slack - pp, 60000.0f);                                       // a slack beyond f16: everything passes
     if (apart) {
-#pragma unroll
-        for (int f = 0; f < 9; f++) feat[f] = 0.0f;
-        feat[9] = oo < 1e15f ? -1.0f : 60000.0f;         // so far out that P itself is uncertain: everything passes
+        // without the linear terms the sum is (u . C)^2 - |C|^2 + r^2 + constant <= r^2 + constant, r <= 120
+        feat[6] = 0.0f; feat[7] = 0.0f; feat[8] = 0.0f;
+        feat[9] = oo < 1e15f ? -20000.0f : 60000.0f;     // so far out that P itself is uncertain: everything passes
     }
     _Float16 x1[10], x2[10];
 #pragma unroll
@@ -519,36 +519,43 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int slots = p.mat_slots;
     int cnt0 = 0, cnt1 = 0;
-    f16x8 a[2], an[2];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; s2++) a[s2] = __builtin_bit_cast(f16x8, s_aimg[s2 * 64 + lane]);
     // Per tile: read the NEXT tile's fragments, issue this tile's four MFMAs (the two halves interleaved, so
     // that no instruction waits for the one before it), compare.  The order matters for correctness, not only
     // for speed: a matrix instruction reads its A and B registers when it starts, which under four waves per
     // SIMD can be long after it was issued, and nothing stops an LDS read or a VALU result from landing in
     // those registers in between.  So the fragment reads are issued BEFORE the MFMAs, into registers of their
-    // own, and every register an MFMA reads stays untouched until its accumulators have been read (which
-    // waits for the instruction to finish): no MFMA is in flight when the loop or the scan ends.
-    for (int t = 0; t < p.ntiles; t++) {
-        const int tn = t + 1 < p.ntiles ? t + 1 : t;
+    // own (two buffers used in turn), and every register an MFMA reads stays untouched until its accumulators
+    // have been read (which waits for the instruction to finish): no MFMA is in flight when the scan ends.
+    auto read_tile = [&](f16x8 (&x)[2], int t) {
+        const int tc = t < p.ntiles ? t : p.ntiles - 1;
 #pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) an[s2] = __builtin_bit_cast(f16x8, s_aimg[(tn * 2 + s2) * 64 + lane]);
+        for (int s2 = 0; s2 < 2; s2++) x[s2] = __builtin_bit_cast(f16x8, s_aimg[(tc * 2 + s2) * 64 + lane]);
         __builtin_amdgcn_sched_barrier(0);
-        f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], as_frag(B[0][0][0], B[0][0][1], B[0][0][2], B[0][0][3]), zero, 0, 0, 0);
-        f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], as_frag(B[1][0][0], B[1][0][1], B[1][0][2], B[1][0][3]), zero, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], as_frag(B[0][1][0], B[0][1][1], B[0][1][2], B[0][1][3]), acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], as_frag(B[1][1][0], B[1][1][1], B[1][1][2], B[1][1][3]), acc1, 0, 0, 0);
+    };
+    auto do_tile = [&](const f16x8 (&x)[2], int t) {
+        f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[0], as_frag(B[0][0][0], B[0][0][1], B[0][0][2], B[0][0][3]), zero, 0, 0, 0);
+        f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[0], as_frag(B[1][0][0], B[1][0][1], B[1][0][2], B[1][0][3]), zero, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[1], as_frag(B[0][1][0], B[0][1][1], B[0][1][2], B[0][1][3]), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[1], as_frag(B[1][1][0], B[1][1][1], B[1][1][2], B[1][1][3]), acc1, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         bool appended = false;
         queue_passes(acc0, t * kTileSpheres, lane, queue, cnt0, appended RT_DIAG_PASS);
         queue_passes(acc1, t * kTileSpheres, lane, queue + slots * 64, cnt1, appended RT_DIAG_PASS);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) a[s2] = an[s2];
         // a half tile adds at most 16 entries to a queue
         if (appended && __ballot(cnt0 > slots - 16 || cnt1 > slots - 16) != 0ULL) {
             drain_matrix(s_geom, queue, slots, cnt0, cnt1, lane, q RT_DIAG_PASS);
             cnt0 = 0; cnt1 = 0;
+        }
+    };
+    f16x8 a[2], b[2];
+    read_tile(a, 0);
+    for (int t = 0; t < p.ntiles; t += 2) {
+        read_tile(b, t + 1);
+        do_tile(a, t);
+        if (t + 1 < p.ntiles) {
+            read_tile(a, t + 2);
+            do_tile(b, t + 1);
         }
     }
 #ifdef RT_DIAG
