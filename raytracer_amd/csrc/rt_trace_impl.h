@@ -521,11 +521,13 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
     int cnt0 = 0, cnt1 = 0;
     // Per tile: read the NEXT tile's fragments, issue this tile's four MFMAs (the two halves interleaved, so
     // that no instruction waits for the one before it), compare.  The order matters for correctness, not only
-    // for speed: a matrix instruction reads its A and B registers when it starts, which under four waves per
-    // SIMD can be long after it was issued, and nothing stops an LDS read or a VALU result from landing in
-    // those registers in between.  So the fragment reads are issued BEFORE the MFMAs, into registers of their
-    // own (two buffers used in turn), and every register an MFMA reads stays untouched until its accumulators
-    // have been read (which waits for the instruction to finish): no MFMA is in flight when the scan ends.
+    // for speed.  A software-pipelined form of this loop, which issued the next tile's LDS reads right AFTER
+    // the MFMAs and let the compiler put them into the registers those MFMAs had just been given (it treats
+    // an operand as read once the instruction is issued), produced wrong accumulators in lanes 48-63 of a few
+    // waves per launch, differently from run to run, at four waves per SIMD on MI355X.  Here the fragment
+    // reads are issued BEFORE the MFMAs, into a buffer of their own (two buffers used in turn), and every
+    // register an MFMA reads stays untouched until its accumulators have been read, which waits for the
+    // instruction to finish; no MFMA is in flight when the scan ends.  This form is deterministic.
     auto read_tile = [&](f16x8 (&x)[2], int t) {
         const int tc = t < p.ntiles ? t : p.ntiles - 1;
 #pragma unroll
