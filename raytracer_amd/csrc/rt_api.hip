@@ -35,7 +35,7 @@ static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES]
 
 namespace {
 
-constexpr int kCounters = 16;                    // 64-bit words: [0] next work unit, [1] rays cast, the rest diagnostics
+constexpr int kCounters = 20;                    // 64-bit words: [0] next work unit, [1] rays cast, the rest diagnostics
 constexpr size_t kScratchCountersBytes = 256;
 constexpr size_t kScratchPartialBytes = (size_t)RT_NOALLOC_SCRATCH_BYTES - kScratchCountersBytes;
 constexpr uint32_t kProgBroken = 0xffffffffu;    // prog_frames of a sequence that must restart at frame 0
@@ -466,6 +466,10 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
                         "pair scan + appends %.2f %%, drain %.2f %%, big spheres %.2f %%, shade %.2f %%, shared-ray search %.2f %%; "
                         "%.0f cycles per wave scan\n", 100.0 * c[9] / tot, 100.0 * c[10] / tot, 100.0 * c[11] / tot, 100.0 * c[12] / tot,
                         100.0 * c[13] / tot, 100.0 * c[14] / tot, 100.0 * c[15] / tot, tot / (double)c[5]);
+                if (c[18] > 0 && c[17] > 0)
+                    fprintf(stderr, "diag: %llu waves lived %.1f %% of the longest wave's %.3f M cycles on average "
+                            "(the rest is the end of the launch: waves that found no more units)\n",
+                            c[18], 100.0 * (double)c[16] / (double)c[18] / (double)c[17], (double)c[17] * 1e-6);
             }
 #endif
 #endif
@@ -779,7 +783,9 @@ static int set_world_impl(const rt_sphere *spheres, size_t count)
     // cx cy, cx cz, cy cz, cx, cy, cz) at 3 f .. 3 f + 2 as (c1, c1, c2); 27, 28: 1, 1; 29, 30: the pieces
     // of k = |C|^2 - r^2; 31: 0.  Rows beyond the scene and the big spheres hold k = 65504 only: the ray's
     // constant is capped at 60000 (rt_trace_impl.h), so their accumulator stays below -5000.
-    int ntiles = n <= kMaxSpheresMatrix ? std::max(1, (n + kTileSpheres - 1) / kTileSpheres) : 0;
+    // Below kMinSpheresMatrix the packed-FP32 scan wins: the matrix scan pays about a hundred instructions per
+    // ray for its features whatever the scene holds (the 3-sphere scene ran 27 ms against 37 ms).
+    int ntiles = (n >= kMinSpheresMatrix && n <= kMaxSpheresMatrix) ? (n + kTileSpheres - 1) / kTileSpheres : 0;
     if (ntiles > 0 && mat_slots(n_pad, ntiles) < kMatSlotsMin) ntiles = 0;      // no room for the queues: vector scan
     double reach = 0.0;
     for (int i = 0; i < n; i++) if (!is_big[i]) reach = std::max(reach, extent[i]);

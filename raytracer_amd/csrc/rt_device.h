@@ -52,6 +52,7 @@ enum { kScanVectorLds = 0, kScanVectorGlobal = 1, kScanMatrix = 2, kScanVariants
 constexpr int kTileSpheres = 32;
 constexpr int kMaxTilesMatrix = 35;        // sphere image 2 KB per tile (+ 0.5 KB of geometry): what leaves room for the queues
 constexpr int kMaxSpheresMatrix = kMaxTilesMatrix * kTileSpheres;
+constexpr int kMinSpheresMatrix = 32;      // smaller scenes: the vector scan (measured break-even 20-40 spheres)
 constexpr int kMatBlockThreads = RT_MAT_THREADS;   // one workgroup per CU: 4 waves per SIMD at 128 VGPRs
 constexpr int kLdsBytes = 160 * 1024;
 // candidate-queue slots (u16) per lane and ray half: what the LDS leaves next to the two images, at least

@@ -727,6 +727,7 @@ __global__ __launch_bounds__(VARIANT == kScanMatrix ? kMatBlockThreads : kBlockT
     pool_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_end);
 #ifdef RT_DIAG
     Diag dg = {0, 0, 0, 0, 0, 0, 0, 0, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
+    const unsigned long long t_wave0 = RT_STAMP();
 #endif
 
     for (;;) {
@@ -1000,6 +1001,10 @@ __global__ __launch_bounds__(VARIANT == kScanMatrix ? kMatBlockThreads : kBlockT
         atomicAdd(&p.counters[13], dg.t_big);
         atomicAdd(&p.counters[14], dg.t_shade);
         atomicAdd(&p.counters[15], dg.t_shared);
+        const unsigned long long life = RT_STAMP() - t_wave0;
+        atomicAdd(&p.counters[16], life);
+        atomicMax(&p.counters[17], life);
+        atomicAdd(&p.counters[18], 1ULL);
     }
 #endif
 #endif

@@ -430,10 +430,12 @@ def _tie_scene(n, seed):
     return s
 
 
-@pytest.mark.parametrize("n,seed", [(1, 0), (2, 1), (7, 2), (65, 3), (130, 4), (257, 5), (600, 6), (1100, 7)])
+@pytest.mark.parametrize("n,seed", [(1, 0), (2, 1), (7, 2), (31, 8), (32, 9), (33, 10), (65, 3), (130, 4), (257, 5),
+                                     (600, 6), (1100, 7), (1120, 11), (1121, 12)])
 def test_strict_build_matches_checker_on_random_scenes(rt, n, seed):
-    """Bit-exact parity away from the two shipped scenes, through both geometry paths (LDS image up
-    to 560 spheres, global memory beyond): hit indices, accumulators, bytes and ray counts."""
+    """Bit-exact parity away from the two shipped scenes, through every scan variant and on both sides of
+    each switch: packed-FP32 scan below 32 spheres, matrix scan from 32 (one tile) to 1120 (35 tiles),
+    packed-FP32 scan with the geometry in global memory beyond: hit indices, accumulators, bytes, ray counts."""
     sph = _tie_scene(n, seed)
     rt.set_world(sph)
     p = rt.default_params()
