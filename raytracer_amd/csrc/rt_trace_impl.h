@@ -703,7 +703,7 @@ __global__ __launch_bounds__(VARIANT == kScanMatrix ? kMatBlockThreads : kBlockT
 
     const uint32_t total = (uint32_t)p.total_units;
 #if !RT_STRICT
-    const double inv_npix = 1.0 / (double)p.npix, inv_width = 1.0 / (double)p.width;
+    const double inv_per_block = 1.0 / (64.0 * (double)p.nchunks), inv_width = 1.0 / (double)p.width;
 #endif
     Lane L;
     L.acc = v3(0.0f, 0.0f, 0.0f);
@@ -759,17 +759,33 @@ __global__ __launch_bounds__(VARIANT == kScanMatrix ? kMatBlockThreads : kBlockT
             const uint32_t asked = (uint32_t)__popcll(want);
             const uint32_t rank = (uint32_t)__popcll(want & ((1ULL << lane) - 1ULL));
             if (active && need_unit && rank < avail) {
+                // Unit u -> (pixel, chunk), pixel-block major: 64 consecutive pixels, all their chunks, then the
+                // next 64 pixels.  The units in flight at any time (a quarter of a million) then cover a few
+                // thousand pixels, so the pools a wave works on one after another lie next to each other in the
+                // image and its rays keep meeting the same spheres; chunk-major order spread them over 68 rows
+                // of the launch, which for one rank's share of a split frame is a quarter of the image.
                 const uint32_t u = pool_next + rank;
+                const uint32_t per_block = 64U * (uint32_t)p.nchunks;
+                uint32_t blk, rem, rowk;
 #if RT_STRICT
-                L.chunk = (int)(u / p.npix);
-                L.pixc = u - (uint32_t)L.chunk * p.npix;
-                uint32_t rowk = L.pixc / p.width;
+                blk = u / per_block;
+                rem = u - blk * per_block;
+#else
+                divmod(u, per_block, inv_per_block, blk, rem);
+#endif
+                const uint32_t left = p.npix - blk * 64U;              // pixels of this block: 64, fewer in the last one
+                if (left >= 64U) {
+                    L.chunk = (int)(rem >> 6);
+                    L.pixc = blk * 64U + (rem & 63U);
+                } else {
+                    L.chunk = (int)(rem / left);
+                    L.pixc = blk * 64U + (rem - (uint32_t)L.chunk * left);
+                }
+#if RT_STRICT
+                rowk = L.pixc / p.width;
                 L.x = L.pixc - rowk * p.width;
 #else
-                uint32_t chunk_u, rowk;
-                divmod(u, p.npix, inv_npix, chunk_u, L.pixc);
                 divmod(L.pixc, p.width, inv_width, rowk, L.x);
-                L.chunk = (int)chunk_u;
 #endif
                 L.y = p.rows ? p.rows[rowk] : part_row_at(rowk, p.tile_rows, p.part_index, p.part_count);
                 L.pixhash = mix32((L.x + L.y * p.width) + mix32(p.seed ^ 0x6A09E667U));
