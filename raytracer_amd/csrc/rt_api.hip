@@ -227,7 +227,8 @@ int resolve_chunk(int chunk_opt, uint32_t width, uint32_t height, int spp, bool 
 
 int scan_variant(const Ctx &g)
 {
-    if (g.ntiles > 0 && !g_vector_scan) return kScanMatrix;
+    if (g.ntiles > 0 && !g_vector_scan)
+        return (g.ntiles <= kMaxTilesMatrix && mat_slots(g.n_pad, g.ntiles) >= kMatSlotsMin) ? kScanMatrix : kScanMatrixGlobal;
     return g.n > kMaxSpheresLds ? kScanVectorGlobal : kScanVectorLds;
 }
 
@@ -370,7 +371,7 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             tp.geom = (const float4 *)g.geom.p; tp.matA = (const float4 *)g.matA.p; tp.matB = (const float4 *)g.matB.p;
             tp.pairs = (const float *)g.pairs.p;
             tp.aimg = (const uint4 *)g.aimg.p; tp.ntiles = g.ntiles;
-            tp.mat_slots = mat_slots(g.n_pad, g.ntiles);
+            tp.mat_slots = scan_variant(g) == kScanMatrixGlobal ? mat_slots(0, 0) : mat_slots(g.n_pad, g.ntiles);
             tp.mat_scale = g.mat_scale; tp.mat_c_near = g.c_near * g.mat_scale;
             tp.n = g.n; tp.n_pad = g.n_pad;
             tp.nbig = g.nbig; memcpy(tp.big, g.big, sizeof tp.big); tp.c_near = g.c_near;
@@ -785,8 +786,7 @@ static int set_world_impl(const rt_sphere *spheres, size_t count)
     // constant is capped at 60000 (rt_trace_impl.h), so their accumulator stays below -5000.
     // Below kMinSpheresMatrix the packed-FP32 scan wins: the matrix scan pays about a hundred instructions per
     // ray for its features whatever the scene holds (the 3-sphere scene ran 27 ms against 37 ms).
-    int ntiles = (n >= kMinSpheresMatrix && n <= kMaxSpheresMatrix) ? (n + kTileSpheres - 1) / kTileSpheres : 0;
-    if (ntiles > 0 && mat_slots(n_pad, ntiles) < kMatSlotsMin) ntiles = 0;      // no room for the queues: vector scan
+    const int ntiles = (n >= kMinSpheresMatrix && n <= kMaxSpheresMatrixGlobal) ? (n + kTileSpheres - 1) / kTileSpheres : 0;
     double reach = 0.0;
     for (int i = 0; i < n; i++) if (!is_big[i]) reach = std::max(reach, extent[i]);
     float mat_scale = 1.0f;

@@ -48,10 +48,15 @@ constexpr int queue_lds_bytes(int block_threads, int slots) { return (block_thre
 //                     32 tile + (l & 31), K entries 16 s + 8 (l >> 5) ..+7).
 //   kScanVectorLds    packed-FP32 vector scan, per-sphere records in LDS (selectable for comparison)
 //   kScanVectorGlobal packed-FP32 vector scan, per-sphere records from global memory (larger scenes)
-enum { kScanVectorLds = 0, kScanVectorGlobal = 1, kScanMatrix = 2, kScanVariants = 3 };
+//   kScanMatrixGlobal the matrix scan for scenes whose image does not fit the LDS: the fragments come from
+//                     global memory (L1 / L2: every wave of the chip reads the same tiles), one tile ahead of
+//                     their use, and so do the per-sphere records of the exact test; the LDS holds the queues
+enum { kScanVectorLds = 0, kScanVectorGlobal = 1, kScanMatrix = 2, kScanMatrixGlobal = 3, kScanVariants = 4 };
+constexpr bool is_matrix(int variant) { return variant == kScanMatrix || variant == kScanMatrixGlobal; }
 constexpr int kTileSpheres = 32;
 constexpr int kMaxTilesMatrix = 35;        // sphere image 2 KB per tile (+ 0.5 KB of geometry): what leaves room for the queues
 constexpr int kMaxSpheresMatrix = kMaxTilesMatrix * kTileSpheres;
+constexpr int kMaxSpheresMatrixGlobal = 65504;   // queue entries are u16 sphere indices (rows of the last tile included)
 constexpr int kMinSpheresMatrix = 32;      // smaller scenes: the vector scan (measured break-even 20-40 spheres)
 constexpr int kMatBlockThreads = RT_MAT_THREADS;   // one workgroup per CU: 4 waves per SIMD at 128 VGPRs
 constexpr int kLdsBytes = 160 * 1024;
@@ -64,7 +69,7 @@ inline int mat_slots(int n_pad, int ntiles)
     const long s = room / ((kMatBlockThreads / 64) * 2 * 64 * 2);
     return (int)(s > kMatSlotsMax ? kMatSlotsMax : s);
 }
-constexpr int block_threads_of(int variant) { return variant == kScanMatrix ? kMatBlockThreads : kBlockThreads; }
+constexpr int block_threads_of(int variant) { return is_matrix(variant) ? kMatBlockThreads : kBlockThreads; }
 constexpr int kMaxSpheresLds = 560;        // up to here the per-sphere records are staged in LDS: 7 workgroups of (9 KB + 14 KB of queues) still fit a CU
 constexpr int kMaxSpheres = 1 << 20;       // beyond kMaxSpheresLds they are read from global memory
 
@@ -151,6 +156,8 @@ int trace_blocks_per_cu_fast(LaunchCache &c, int variant, size_t lds_bytes);
 // Dynamic LDS of a trace kernel: [matrix image][geometry image][candidate queues].
 inline size_t trace_lds_bytes(int variant, bool strict, int n_pad, int ntiles)
 {
+    if (variant == kScanMatrixGlobal)
+        return (size_t)(kMatBlockThreads / 64) * 2 * mat_slots(0, 0) * 64 * sizeof(uint16_t);
     if (variant == kScanMatrix)
         return (size_t)ntiles * 128 * sizeof(uint4) + (size_t)n_pad * sizeof(float4) +
                (size_t)(kMatBlockThreads / 64) * 2 * mat_slots(n_pad, ntiles) * 64 * sizeof(uint16_t);

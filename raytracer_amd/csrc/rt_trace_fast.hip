@@ -12,6 +12,7 @@ typedef void (*trace_fn)(const TraceParams);
 static trace_fn kernel_for(int mode, int variant)
 {
     if (variant == kScanMatrix) return mode ? fast_build::trace_kernel<1, kScanMatrix> : fast_build::trace_kernel<0, kScanMatrix>;
+    if (variant == kScanMatrixGlobal) return mode ? fast_build::trace_kernel<1, kScanMatrixGlobal> : fast_build::trace_kernel<0, kScanMatrixGlobal>;
     if (variant == kScanVectorGlobal) return mode ? fast_build::trace_kernel<1, kScanVectorGlobal> : fast_build::trace_kernel<0, kScanVectorGlobal>;
     return mode ? fast_build::trace_kernel<1, kScanVectorLds> : fast_build::trace_kernel<0, kScanVectorLds>;
 }

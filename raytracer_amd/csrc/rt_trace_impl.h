@@ -437,13 +437,16 @@ __device__ __forceinline__ void queue_passes(const f32x16 &acc, int first, int l
 
 // hit() (Main.c:688-713) as matrix filter + exact test; u is the unit direction.
 //
-// Error budget of the filter, in the scaled frame (S = |O'| + max|C'|).  A feature is x = x1 + x2 + e with
-// |e| <= 2^-24 |x| (two f16 pieces, round to nearest); the product x2 y2 is dropped (<= 2^-24 |x||y|); the
-// features themselves carry f32 roundings (a few 2^-24 S^2 in all).  The MFMA sums the 16 exact products of
-// an instruction and its C input in a window of 24 bits below the largest of them and truncates what lies
-// below (measured: tools/mfma_prec): at most 2^-23 of the largest term per term, 32 terms, every term
-// <= S^2, hence <= 2^-18 S^2.  slack = 2^-16 S^2 (+ 0.01 for f16 subnormal pieces) is four times that bound
-// and also covers the rounding of the exact test that decides afterwards.
+// Error budget of the filter, in the scaled frame (S = |O'| + max|C'|; the absolute values of the 31 terms sum
+// to at most 2 S^2).  Pieces: a feature is x = x1 + x2 + e with |e| <= 2^-24 |x| (two f16 pieces, round to
+// nearest), the product x2 y2 is dropped: 3 * 2^-24 of every term, 2^-21.4 S^2.  The f32 roundings of the
+// features: 2^-21 S^2.  Moving the origin to the nearest point of the line: 2^-20.2 S^2 (below).  The MFMA sums
+// the 16 exact products of an instruction and its C input in a window of 24 bits below the largest of them and
+// truncates what lies below (measured: tools/mfma_prec.hip): 32 terms, each <= S^2, plus the rounding of the two
+// results: 2^-19 S^2 + 2^-22 S^2.  Sum 2^-18.0 S^2; the strict build adds 2^-21 S^2 for its hardware rsqrt and
+// for the rounding of the reference-order exact test that decides afterwards.  slack = 2^-17 S^2 (+ 0.01 for
+// f16 subnormal pieces) is twice the bound; measured over 16384 rays x all spheres of three scenes the
+// accumulator is within 2^-21.4 S^2 of the discriminant (tools/mfma_scan_proto.hip).
 __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const float4 *s_geom, const uint4 *s_aimg, uint16_t *queue,
                                                     int lane, float ux, float uy, float uz, Probe &q RT_DIAG_ARG)
 {
@@ -458,7 +461,10 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
     const float ox = q.ox * p.mat_scale, oy = q.oy * p.mat_scale, oz = q.oz * p.mat_scale;
     const float oo = fmaf(oz, oz, fmaf(oy, oy, ox * ox));
     const float reach = __builtin_amdgcn_sqrtf(oo) * 1.0000005f + p.mat_c_near;
-    const float slack = fmaf(reach * reach, 1.52587890625e-5f, 0.01f);            // 2^-16
+#ifndef RT_MAT_SLACK
+#define RT_MAT_SLACK 7.62939453125e-6f                                            // 2^-17
+#endif
+    const float slack = fmaf(reach * reach, RT_MAT_SLACK, 0.01f);
     // The discriminant does not change when the origin slides along the ray: take the point of the line
     // nearest to the frame's origin, P = O' - (u . O') u.  Then u . P = 0 up to rounding (covered by the
     // slack: |dP| <= 7 * 2^-24 |O'|, which moves the discriminant by <= 2^-20 S^2), the features are
@@ -670,8 +676,8 @@ __device__ __forceinline__ void camera_ray(const TraceParams &p, Lane &L)
 // kScanVectorGlobal serves scenes whose geometry image does not fit the LDS next to the queues: the
 // per-sphere records (exact test, shading) come from global memory through the vector L1 instead.
 template <int MODE, int VARIANT>
-__global__ __launch_bounds__(VARIANT == kScanMatrix ? kMatBlockThreads : kBlockThreads,
-                             VARIANT == kScanMatrix ? kMatBlockThreads / 256 : RT_MIN_WAVES) void trace_kernel(const TraceParams p)
+__global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThreads,
+                             is_matrix(VARIANT) ? kMatBlockThreads / 256 : RT_MIN_WAVES) void trace_kernel(const TraceParams p)
 {
     extern __shared__ float4 lds[];
     const int lane = (int)__lane_id();
@@ -687,6 +693,10 @@ __global__ __launch_bounds__(VARIANT == kScanMatrix ? kMatBlockThreads : kBlockT
         s_aimg = img; s_geom = gm;
         s_matA = p.matA; s_matB = p.matB;
         queue16 = reinterpret_cast<uint16_t *>(gm + p.n_pad) + (threadIdx.x >> 6) * (2 * p.mat_slots * 64);
+        queue = nullptr;
+    } else if (VARIANT == kScanMatrixGlobal) {
+        s_aimg = p.aimg; s_geom = p.geom; s_matA = p.matA; s_matB = p.matB;
+        queue16 = reinterpret_cast<uint16_t *>(lds) + (threadIdx.x >> 6) * (2 * p.mat_slots * 64);
         queue = nullptr;
     } else if (VARIANT == kScanVectorGlobal) {
         s_geom = p.geom; s_matA = p.matA; s_matB = p.matB;
@@ -833,7 +843,7 @@ __global__ __launch_bounds__(VARIANT == kScanMatrix ? kMatBlockThreads : kBlockT
             const float inv = (q.a > 0.0f) ? __builtin_amdgcn_rsqf(q.a) : 0.0f;
             const unsigned long long live = __ballot(active);
             if (__popcll(live) <= p.coop_max) shared_ray_hit(p, s_geom, lane, live, q);
-            else if (VARIANT == kScanMatrix) scan_spheres_matrix(p, s_geom, s_aimg, queue16, lane, q.dx * inv, q.dy * inv, q.dz * inv, q RT_DIAG_PASS);
+            else if (is_matrix(VARIANT)) scan_spheres_matrix(p, s_geom, s_aimg, queue16, lane, q.dx * inv, q.dy * inv, q.dz * inv, q RT_DIAG_PASS);
             else scan_spheres(p, s_geom, queue, lane, q.dx * inv, q.dy * inv, q.dz * inv, 7.6293945e-6f, q RT_DIAG_PASS);
             if (!(q.a > 0.0f)) {
                 // a zero or NaN direction gives the filter nothing to work with: test everything
@@ -844,7 +854,7 @@ __global__ __launch_bounds__(VARIANT == kScanMatrix ? kMatBlockThreads : kBlockT
 #else
         const unsigned long long live = __ballot(active);
         if (__popcll(live) <= p.coop_max) shared_ray_hit(p, s_geom, lane, live, q);
-        else if (VARIANT == kScanMatrix) scan_spheres_matrix(p, s_geom, s_aimg, queue16, lane, q.dx, q.dy, q.dz, q RT_DIAG_PASS);
+        else if (is_matrix(VARIANT)) scan_spheres_matrix(p, s_geom, s_aimg, queue16, lane, q.dx, q.dy, q.dz, q RT_DIAG_PASS);
         else scan_spheres(p, s_geom, queue, lane, q.dx, q.dy, q.dz, 1.9073486e-6f, q RT_DIAG_PASS);   // 2^-19
 #ifdef RT_DIAG
         if (__popcll(live) <= p.coop_max) dg.shared_rays += (uint32_t)__popcll(live); else dg.scan_lanes += (uint32_t)__popcll(live);

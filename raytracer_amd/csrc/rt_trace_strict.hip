@@ -54,6 +54,7 @@ typedef void (*trace_fn)(const TraceParams);
 static trace_fn kernel_for(int mode, int variant)
 {
     if (variant == kScanMatrix) return mode ? strict_build::trace_kernel<1, kScanMatrix> : strict_build::trace_kernel<0, kScanMatrix>;
+    if (variant == kScanMatrixGlobal) return mode ? strict_build::trace_kernel<1, kScanMatrixGlobal> : strict_build::trace_kernel<0, kScanMatrixGlobal>;
     if (variant == kScanVectorGlobal) return mode ? strict_build::trace_kernel<1, kScanVectorGlobal> : strict_build::trace_kernel<0, kScanVectorGlobal>;
     return mode ? strict_build::trace_kernel<1, kScanVectorLds> : strict_build::trace_kernel<0, kScanVectorLds>;
 }

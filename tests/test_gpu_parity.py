@@ -430,12 +430,40 @@ def _tie_scene(n, seed):
     return s
 
 
+def test_every_scan_variant_gives_the_same_image(tmp_path):
+    """The matrix scan (image in LDS: 40 and 600 spheres; image in global memory: 1300 and 5000) and the
+    packed-FP32 scan (RTMI_SCAN=vector: geometry in LDS up to 560 spheres, in global memory beyond) are two
+    filters in front of the same exact test: hit indices, accumulator bits and ray counts must be equal in
+    both builds, and equal from run to run."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    worker = os.path.join(ROOT, "tests", "scan_variant_worker.py")
+    res = {}
+    for name, env in (("matrix", {}), ("vector", {"RTMI_SCAN": "vector"})):
+        out = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, worker, out], env=dict(os.environ, **env), cwd=ROOT,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        res[name] = np.load(out)
+    keys = sorted(res["matrix"].files)
+    assert keys == sorted(res["vector"].files) and len(keys) == 4 * 2 * 2 * 3
+    for k in keys:
+        a, b = res["matrix"][k], res["vector"][k]
+        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
+                              b.view(np.uint32) if b.dtype == np.float32 else b), k
+        if "_0_" in k:                                   # first against second run of the same process
+            k1 = k.replace("_0_", "_1_")
+            assert np.array_equal(res["matrix"][k].tobytes(), res["matrix"][k1].tobytes()), k
+
+
 @pytest.mark.parametrize("n,seed", [(1, 0), (2, 1), (7, 2), (31, 8), (32, 9), (33, 10), (65, 3), (130, 4), (257, 5),
-                                     (600, 6), (1100, 7), (1120, 11), (1121, 12)])
+                                     (600, 6), (1100, 7), (1120, 11), (1121, 12), (2500, 13)])
 def test_strict_build_matches_checker_on_random_scenes(rt, n, seed):
     """Bit-exact parity away from the two shipped scenes, through every scan variant and on both sides of
-    each switch: packed-FP32 scan below 32 spheres, matrix scan from 32 (one tile) to 1120 (35 tiles),
-    packed-FP32 scan with the geometry in global memory beyond: hit indices, accumulators, bytes, ray counts."""
+    each switch: packed-FP32 scan below 32 spheres, matrix scan with its image in LDS from 32 (one tile) to
+    1120 spheres (35 tiles), matrix scan with the image read from global memory beyond: hit indices,
+    accumulators, bytes, ray counts."""
     sph = _tie_scene(n, seed)
     rt.set_world(sph)
     p = rt.default_params()
