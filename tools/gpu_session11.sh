@@ -2,8 +2,9 @@
 # Final evidence of the round under gpurun_out/r2b/ (copied into profiles/r2b_final/ afterwards).
 set -o pipefail
 R=$PWD
-O=$R/gpurun_out/r2b
-bash tools/profile_round.sh r2b > gpurun_out/r2b_profile.log 2>&1 || { echo "profile_round failed"; tail -5 gpurun_out/r2b_profile.log; exit 1; }
+N=${1:-r2c}
+O=$R/gpurun_out/$N
+bash tools/profile_round.sh $N > gpurun_out/${N}_profile.log 2>&1 || { echo "profile_round failed"; tail -5 gpurun_out/${N}_profile.log; exit 1; }
 cd $R
 RTMI_LIB=$R/tools/librtmi_stamps.so timeout -k 10 120 python tools/quick.py 1920 125 2 0 > $O/stamps_fast.log 2>&1 || exit 1
 RTMI_LIB=$R/tools/librtmi_stamps.so timeout -k 10 120 python tools/quick.py 1920 125 2 1 > $O/stamps_strict.log 2>&1 || exit 1
@@ -23,11 +24,12 @@ for spp in 1000 125 8; do RT_CHUNK=-1 timeout -k 10 100 python tools/quick.py 19
 } > $O/configs.txt 2>&1 || { cat $O/configs.txt; exit 1; }
 {
 echo "# tools/quick.py 1920 20 2 0 genN (rt_scene_generate with half extent N), fast build, RT_CHUNK_AUTO, one GPU session"
-for g in 14 16 22 32 45 64; do RT_CHUNK=-1 timeout -k 10 100 python tools/quick.py 1920 20 2 0 gen$g | tail -1 || exit 1; done
+for g in 14 16 22 32 45 64 90; do RT_CHUNK=-1 timeout -k 10 100 python tools/quick.py 1920 20 2 0 gen$g | tail -1 || exit 1; done
 } > $O/scene_size_sweep.txt 2>&1 || { cat $O/scene_size_sweep.txt; exit 1; }
 timeout -k 10 300 python tools/part_scaling.py > $O/part_scaling.txt 2>&1 || { cat $O/part_scaling.txt; exit 1; }
 timeout -k 10 300 python tools/part_scaling2.py >> $O/part_scaling.txt 2>&1 || exit 1
 timeout -k 10 200 python tools/progressive_fps.py > $O/progressive_fps.txt 2>&1 || exit 1
+RTMI_LIB=$R/tools/librtmi_stamps.so timeout -k 10 300 python tools/part_stamps.py > $O/part_stamps.log 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 240 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_parts -o p -- python3 $R/tools/part_scaling.py > $O/pmc_parts.log 2> $O/pmc_parts.err || exit 1
 cp $(find $O/pmc_parts -name '*counter_collection.csv' | head -1) $O/pmc_parts.csv && rm -rf $O/pmc_parts
