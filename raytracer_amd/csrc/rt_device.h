@@ -34,11 +34,12 @@ constexpr int kBlockThreads = 256;
 constexpr int kQueueSlotsFast = 14;        // candidate-queue slots per lane
 constexpr int kQueueSlotsStrict = 16;
 constexpr int queue_lds_bytes(int block_threads, int slots) { return (block_threads / 64) * slots * 64 * 4; }   // waves x slots x 64 lanes x u32
-// The sphere scan comes in three variants.
+// The sphere scan comes in four variants.
 //   kScanMatrix       scenes whose matrix image fits the LDS: the conservative filter runs on the matrix
-//                     cores.  The discriminant of (ray, sphere) with a unit direction d, g = d.O,
-//                     w = 2 (O - g d) is
-//                         disc = sum_ij (d_i d_j)(c_i c_j) + w.C + (g^2 - |O|^2) - (|C|^2 - r^2),
+//                     cores.  The discriminant of (ray, sphere) with a unit direction d and the origin slid
+//                     along the ray to the point of the line nearest to the frame's origin,
+//                     P = O - (d.O) d (so d.P = 0), is
+//                         disc = sum_ij (d_i d_j)(c_i c_j) + 2 P.C - |P|^2 - (|C|^2 - r^2),
 //                     one inner product of ten ray features with ten sphere features.  In a frame scaled
 //                     by a power of two (spheres within 120 of the origin) each f32 feature is split into
 //                     two f16 pieces x = x1 + x2 and the products x1 y1 + x1 y2 + x2 y1 are summed by
