@@ -48,7 +48,9 @@ def test_two_rank_json_shape():
     assert "cpu_baseline" not in out and "strict" not in out          # N = 1 legs only
     r = out["roofline"]
     assert r["bound"] == "valu_fp32" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
-    assert abs(r["executed_frac"] - r["frac"] * 14 / 18) < 1e-3 and r["traffic"] is None
+    m = r["matrix"]
+    assert m["bound"] == "mfma" and m["peak"] == 2500.0 and abs(m["achieved"] - r["achieved"] * 62 / 18) < 1e-2
+    assert abs(m["frac"] - m["achieved"] / 2500.0) < 1e-3 and r["traffic"] is None
     assert out["config"]["chunk_spp"] == 8 and "parity_bar" in out["config"]
 
 
