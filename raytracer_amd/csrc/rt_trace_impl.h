@@ -211,9 +211,8 @@ struct Probe {
 };
 
 // hit_sphere (Main.c:625-672) for sphere i, up to the accept decision.
-__device__ __forceinline__ void exact_test(const float4 *s_geom, int i, Probe &q)
+__device__ __forceinline__ void exact_test_record(const float4 g, int i, Probe &q)
 {
-    const float4 g = s_geom[i];
     const float ocx = g.x - q.ox, ocy = g.y - q.oy, ocz = g.z - q.oz;
 #if RT_STRICT
     const float h = q.dx * ocx + q.dy * ocy + q.dz * ocz;
@@ -239,6 +238,11 @@ __device__ __forceinline__ void exact_test(const float4 *s_geom, int i, Probe &q
         if (t > q.tmin && (t < q.closest || (t == q.closest && i < q.hit))) { q.closest = t; q.hit = i; }
     }
 #endif
+}
+
+__device__ __forceinline__ void exact_test(const float4 *s_geom, int i, Probe &q)
+{
+    exact_test_record(s_geom[i], i, q);
 }
 
 #ifdef RT_DIAG
@@ -383,16 +387,30 @@ __device__ __forceinline__ void drain_matrix(const float4 *s_geom, const uint16_
     const int mine = h ? (int)c[1] : (int)c[0], theirs = h ? (int)c[0] : (int)c[1];
     const int total = mine + theirs;
     const uint16_t *qa = queue + h * (slots * 64);
+    // Entry j of the lane's ray: its own queue first, then the partner's.  An entry holds the tile's first
+    // sphere plus the accumulator's row offset; the half of the lane that queued it adds 4 (its rows are
+    // (i & 3) + 8 (i >> 2) + 4 (lane >> 5)).  Lanes beyond their last entry read slot 0 and test sphere 0
+    // into nothing (the index is replaced before it is used as an address).
+    auto sphere_of = [&](int j) {
+        const bool own = j < mine;
+        const int slot = own ? j : j - mine;
+        const int at = j < total ? slot * 64 + (own ? lane : (lane ^ 32)) : lane;
+        const int v = (int)qa[at] + (own ? 4 * h : 4 - 4 * h);
+        return j < total ? v : 0;
+    };
+    // Two LDS round trips per candidate (index, then record) would leave every step waiting: the index is
+    // read two steps ahead and the record one step ahead of the test.
+    int i0 = sphere_of(0);
+    int i1 = sphere_of(1);
+    float4 g0 = s_geom[i0];
     for (int j = 0; __ballot(j < total) != 0ULL; j++) {
 #ifdef RT_DIAG
         dg.drain_iters++; dg.drain_lanes += (uint32_t)__popcll(__ballot(j < total));
 #endif
-        if (j < total) {
-            // an entry holds the tile's first sphere plus the accumulator's row offset; the half of the lane
-            // that queued it adds 4 (its rows are (i & 3) + 8 (i >> 2) + 4 (lane >> 5))
-            const int i = j < mine ? (int)qa[j * 64 + lane] + 4 * h : (int)qa[(j - mine) * 64 + (lane ^ 32)] + 4 - 4 * h;
-            exact_test(s_geom, i, q);
-        }
+        const float4 g1 = s_geom[i1];
+        const int i2 = sphere_of(j + 2);
+        if (j < total) exact_test_record(g0, i0, q);
+        g0 = g1; i0 = i1; i1 = i2;
     }
 #ifdef RT_DIAG
     dg.t_drain += RT_STAMP() - t0;
