@@ -74,7 +74,7 @@ struct Ctx {
     int nbig = 0;
     int big[kMaxBig] = {0};
     float c_near = 0.0f;
-    DevBuf geom, matA, matB, pairs, aimg;
+    DevBuf geom, matA, matB, pairs, aimg, orig;
     int ntiles = 0;              // 32-sphere tiles of the matrix scan's image (0: the scene is too large for it)
     float mat_scale = 1.0f;      // power-of-two scale of the matrix scan's frame
     // scratch
@@ -93,6 +93,7 @@ struct Ctx {
 Ctx g_ctx[kMaxContexts];
 int g_nctx = 0;
 bool g_vector_scan = false;      // RTMI_SCAN=vector in the environment at rt_init: packed-FP32 scan for every scene size
+bool g_caller_order = false;     // RTMI_ORDER=caller in the environment at rt_init: spheres stay in the caller's order on the device (comparison runs)
 
 thread_local char g_err[512] = "";      // per thread: the worker threads of a multi-device frame report through it
 
@@ -369,6 +370,7 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             put3(tp.cam.ddu, cam->defocus_disk_u); put3(tp.cam.ddv, cam->defocus_disk_v);
             tp.cam.defocus_angle = cam->defocus_angle;
             tp.geom = (const float4 *)g.geom.p; tp.matA = (const float4 *)g.matA.p; tp.matB = (const float4 *)g.matB.p;
+            tp.orig = (const int32_t *)g.orig.p;
             tp.pairs = (const float *)g.pairs.p;
             tp.aimg = (const uint4 *)g.aimg.p; tp.ntiles = g.ntiles;
             tp.mat_slots = scan_variant(g) == kScanMatrixGlobal ? mat_slots(0, 0) : mat_slots(g.n_pad, g.ntiles);
@@ -494,6 +496,7 @@ void release_ctx(Ctx &g)
     if (g.stream) (void)hipStreamSynchronize(g.stream);
     g.geom.release(); g.matA.release(); g.matB.release(); g.pairs.release();
     g.aimg.release();
+    g.orig.release();
     g.partial.release(); g.running.release(); g.rows.release(); g.counters.release(); g.rgba.release(); g.accum.release(); g.hit.release();
     if (g.ev0) (void)hipEventDestroy(g.ev0);
     if (g.ev1) (void)hipEventDestroy(g.ev1);
@@ -689,6 +692,8 @@ int rt_init_devices(const int *devices, int count)
         shutdown_all();
         const char *scan = getenv("RTMI_SCAN");
         g_vector_scan = scan && strcmp(scan, "vector") == 0;
+        const char *ord = getenv("RTMI_ORDER");
+        g_caller_order = ord && strcmp(ord, "caller") == 0;
         if (!devices || count < 1 || count > kMaxContexts)
             return fail(RT_ERR_ARG, "rt_init_devices: between 1 and %d devices (got %d)", kMaxContexts, count);
         int ndev = 0;
@@ -719,18 +724,81 @@ int rt_init_devices(const int *devices, int count)
 
 int rt_init(int device) { return rt_init_devices(&device, 1); }
 
-static int set_world_impl(const rt_sphere *spheres, size_t count)
+// Interleaves the low 10 bits of x, y, z: the position of a cell of a 1024^3 grid along the Z-order curve.
+static uint32_t morton3(uint32_t x, uint32_t y, uint32_t z)
+{
+    auto spread = [](uint32_t v) {
+        v &= 0x3ffU;
+        v = (v | (v << 16)) & 0x030000ffU;
+        v = (v | (v << 8)) & 0x0300f00fU;
+        v = (v | (v << 4)) & 0x030c30c3U;
+        v = (v | (v << 2)) & 0x09249249U;
+        return v;
+    };
+    return spread(x) | (spread(y) << 1) | (spread(z) << 2);
+}
+
+// Device order of the spheres: along the Z-order curve through their centres (cubic cells over the bounding box
+// of the finite centres; equal cells keep the caller's order), so that the 32 spheres of a tile of the matrix scan
+// are neighbours in space.  The rays of a wave start near each other, and what they pass then sits in few tiles:
+// the appends, which cost per half tile that holds a candidate, fell by a quarter on the 488-sphere scene (4 % of
+// the kernel time; a shuffled list ran 6 % slower than the caller's order, which was sorted by one coordinate).
+// Nothing a caller sees depends on the order: hits are reported by the caller's index and equal distances go to
+// the lower caller's index (order[] travels to the device for that).
+static std::vector<int32_t> device_order(const rt_sphere *spheres, int n)
+{
+    std::vector<int32_t> order(n);
+    for (int i = 0; i < n; i++) order[i] = i;
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    bool any = false;
+    auto coord = [&](int i, int a) { return (double)(a == 0 ? spheres[i].center.x : a == 1 ? spheres[i].center.y : spheres[i].center.z); };
+    for (int i = 0; i < n; i++) {
+        if (!(std::isfinite(coord(i, 0)) && std::isfinite(coord(i, 1)) && std::isfinite(coord(i, 2)))) continue;
+        for (int a = 0; a < 3; a++) {
+            const double c = coord(i, a);
+            if (!any || c < lo[a]) lo[a] = c;
+            if (!any || c > hi[a]) hi[a] = c;
+        }
+        any = true;
+    }
+    const double span = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+    if (!any || !(span > 0.0) || !std::isfinite(span)) return order;
+    std::vector<uint32_t> key(n, 0xffffffffU);
+    for (int i = 0; i < n; i++) {
+        uint32_t cell[3];
+        bool ok = true;
+        for (int a = 0; a < 3; a++) {
+            const double c = coord(i, a);
+            if (!std::isfinite(c)) { ok = false; break; }
+            const double q = (c - lo[a]) / span * 1023.0;
+            cell[a] = (uint32_t)std::min(1023.0, std::max(0.0, q));
+        }
+        if (ok) key[i] = morton3(cell[0], cell[1], cell[2]);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+    return order;
+}
+
+static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
 {
     if (g_nctx == 0) return fail(RT_ERR_STATE, "rt_set_world: rt_init has not been called");
-    if (!spheres && count) return fail(RT_ERR_ARG, "rt_set_world: null sphere array");
+    if (!caller_spheres && count) return fail(RT_ERR_ARG, "rt_set_world: null sphere array");
     if (count > (size_t)kMaxSpheres)
         return fail(RT_ERR_ARG, "rt_set_world: %zu spheres; at most %d are supported", count, kMaxSpheres);
     for (size_t i = 0; i < count; i++)
-        if (spheres[i].mat_type < RT_MAT_LAMBERTIAN || spheres[i].mat_type > RT_MAT_DIELECTRIC)
-            return fail(RT_ERR_ARG, "rt_set_world: sphere %zu has unsupported material type %d", i, spheres[i].mat_type);
+        if (caller_spheres[i].mat_type < RT_MAT_LAMBERTIAN || caller_spheres[i].mat_type > RT_MAT_DIELECTRIC)
+            return fail(RT_ERR_ARG, "rt_set_world: sphere %zu has unsupported material type %d", i, caller_spheres[i].mat_type);
     DeviceGuard keep;
     const int n = (int)count;
     const int n_pad = n == 0 ? kGeomPad : ((n + kGeomPad - 1) / kGeomPad) * kGeomPad;
+    // From here on "sphere i" is the i-th sphere in device order; orig[i] is its index in the caller's list.
+    std::vector<int32_t> orig = g_caller_order ? std::vector<int32_t>() : device_order(caller_spheres, n);
+    if (g_caller_order) { orig.resize(n); for (int i = 0; i < n; i++) orig[i] = i; }
+    std::vector<rt_sphere> in_order(n > 0 ? n : 1);
+    for (int i = 0; i < n; i++) in_order[i] = caller_spheres[orig[i]];
+    const rt_sphere *spheres = in_order.data();
+    orig.resize(n_pad);
+    for (int i = n; i < n_pad; i++) orig[i] = i;
     std::vector<float4> geom(n_pad), matA(n > 0 ? n : 1), matB(n > 0 ? n : 1);
     for (int i = 0; i < n_pad; i++) {
         if (i < n) {
@@ -831,6 +899,8 @@ static int set_world_impl(const rt_sphere *spheres, size_t count)
         }
         HIP_TRY(g.pairs.reserve(pairs.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(g.pairs.p, pairs.data(), pairs.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(g.orig.reserve(orig.size() * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(g.orig.p, orig.data(), orig.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         HIP_TRY(g.geom.reserve(geom.size() * sizeof(float4)));
         HIP_TRY(g.matA.reserve(matA.size() * sizeof(float4)));
         HIP_TRY(g.matB.reserve(matB.size() * sizeof(float4)));

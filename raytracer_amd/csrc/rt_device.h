@@ -10,7 +10,8 @@
 
 namespace rtmi {
 
-// Device-resident world in structure-of-arrays form.  One float4 per sphere and array:
+// Device-resident world in structure-of-arrays form, in DEVICE ORDER (rt_set_world sorts the spheres along a
+// space-filling curve; orig[] maps back to the caller's indices).  One float4 per sphere and array:
 //   geom[i] = { cx, cy, cz, r*r }            -- all hit_sphere (Main.c:625-653) needs to reject
 //   matA[i] = { albedo.r, albedo.g, albedo.b, fuzz }
 //   matB[i] = { refraction_index, bits(mat_type), 1.0f/r, r }
@@ -84,6 +85,7 @@ struct TraceParams {
     const float4 *geom;                    // [n_pad]
     const float4 *matA;                    // [n]
     const float4 *matB;                    // [n]
+    const int32_t *orig;                   // [n_pad] device order -> index in the caller's list (hit indices, ties)
     const float *pairs;                    // [n_pad / 2][8]
     const uint4 *aimg;                     // [ntiles][2][64] f16 fragments of the matrix scan, or nullptr
     float mat_scale;                       // power-of-two scale of the matrix scan's frame

@@ -207,8 +207,16 @@ struct Probe {
     float a;            // |d|^2, Main.c:648
 #endif
     float closest;
-    int hit;
+    int hit;                    // in device order
+    const int32_t *orig;        // device order -> the caller's index (wave-uniform; read only to settle equal distances)
 };
+
+// Spheres are resolved out of order and the device order is not the caller's: of two hits at exactly the same
+// distance the one with the lower index in the CALLER's list wins, as in hit()'s in-order strict '<'.
+__device__ __forceinline__ bool wins_tie(const Probe &q, int i)
+{
+    return q.hit >= 0 && q.orig[i] < q.orig[q.hit];
+}
 
 // hit_sphere (Main.c:625-672) for sphere i, up to the accept decision.
 __device__ __forceinline__ void exact_test_record(const float4 g, int i, Probe &q)
@@ -225,7 +233,10 @@ __device__ __forceinline__ void exact_test_record(const float4 g, int i, Probe &
         // and then the far root is tried, or because it is >= closest, and then the far root,
         // which is not smaller, fails too: the choice of root does not depend on closest.
         if (!(q.tmin < root)) root = (h + sq) / q.a;
-        if (q.tmin < root && (root < q.closest || (root == q.closest && i < q.hit))) { q.closest = root; q.hit = i; }
+        if (q.tmin < root) {
+            if (root < q.closest) { q.closest = root; q.hit = i; }
+            else if (__builtin_expect(root == q.closest, 0)) { if (wins_tie(q, i)) q.hit = i; }
+        }
     }
 #else
     const float h = fmaf(q.dz, ocz, fmaf(q.dy, ocy, q.dx * ocx));
@@ -235,7 +246,10 @@ __device__ __forceinline__ void exact_test_record(const float4 g, int i, Probe &
         const float sq = rt_sqrt(disc);
         const float t0 = h - sq;
         const float t = (t0 > q.tmin) ? t0 : (h + sq);
-        if (t > q.tmin && (t < q.closest || (t == q.closest && i < q.hit))) { q.closest = t; q.hit = i; }
+        if (t > q.tmin) {
+            if (t < q.closest) { q.closest = t; q.hit = i; }
+            else if (__builtin_expect(t == q.closest, 0)) { if (wins_tie(q, i)) q.hit = i; }
+        }
     }
 #endif
 }
@@ -613,12 +627,23 @@ __device__ __forceinline__ void shared_ray_hit(const TraceParams &p, const float
 #endif
         t.closest = 3.402823466e+38f;
         t.hit = -1;
+        t.orig = q.orig;
         for (int i = lane; i < p.n; i += 64) exact_test(s_geom, i, t);
-        for (int off = 32; off > 0; off >>= 1) {
-            const float oc = __shfl_xor(t.closest, off);
-            const int oh = __shfl_xor(t.hit, off);
-            if (oc < t.closest || (oc == t.closest && oh < t.hit)) { t.closest = oc; t.hit = oh; }
+        auto merge = [&](float oc, int oh) {
+            if (oc < t.closest) { t.closest = oc; t.hit = oh; }
+            else if (oc == t.closest && oh >= 0 && wins_tie(t, oh)) t.hit = oh;
+        };
+        // Butterfly over the wave without per-lane address registers (the kernel keeps none alive for this rare
+        // path): lane ^ 32 through the half swap, lane ^ 16 .. 1 through the LDS crossbar's bit-mask mode.
+        {
+            const auto c = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, t.closest), __builtin_bit_cast(unsigned, t.closest), false, false);
+            const auto h = __builtin_amdgcn_permlane32_swap((unsigned)t.hit, (unsigned)t.hit, false, false);
+            merge(__builtin_bit_cast(float, lane < 32 ? c[1] : c[0]), (int)(lane < 32 ? h[1] : h[0]));
         }
+#define RT_XOR_STEP(OFF) merge(__builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, t.closest), ((OFF) << 10) | 0x1f)), \
+                               __builtin_amdgcn_ds_swizzle(t.hit, ((OFF) << 10) | 0x1f))
+        RT_XOR_STEP(16); RT_XOR_STEP(8); RT_XOR_STEP(4); RT_XOR_STEP(2); RT_XOR_STEP(1);
+#undef RT_XOR_STEP
         if (lane == src) { q.closest = t.closest; q.hit = t.hit; }
     }
 }
@@ -851,6 +876,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
         q.tmin = L.tmin;
         q.closest = 3.402823466e+38f;          // max_f32, Main.c:734
         q.hit = -1;
+        q.orig = p.orig;
 #if RT_STRICT
         {
             // The filter needs a unit direction only to stay conservative, so hardware rsqrt
@@ -910,7 +936,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
         // ---- shade: ray_color's loop body, Main.c:730-759 ------------------------------
         if (active) {
             rays++;
-            if (p.hit_index != nullptr && L.bounce == 0 && L.s == p.spp - 1) p.hit_index[L.pixc] = hit;
+            if (p.hit_index != nullptr && L.bounce == 0 && L.s == p.spp - 1) p.hit_index[L.pixc] = hit >= 0 ? p.orig[hit] : -1;
             bool done = false;
             V3 add_col = v3(0.0f, 0.0f, 0.0f);
 #if RT_STRICT
