@@ -1,6 +1,7 @@
 """Worker of test_gpu_parity.py::test_every_scan_variant_gives_the_same_image: renders a few scenes with the
 strict and the fast build and writes hit indices, accumulators and ray counts to an .npz file.  The test
-runs it twice, once as is and once with RTMI_SCAN=vector (packed-FP32 scan for every scene size)."""
+runs it once as is, once with RTMI_SCAN=vector (packed-FP32 scan for every scene size) and with RTMI_ORDER=caller
+(spheres kept in the caller's order on the device)."""
 import os
 import sys
 

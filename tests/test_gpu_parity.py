@@ -434,24 +434,31 @@ def test_every_scan_variant_gives_the_same_image(tmp_path):
     """The matrix scan (image in LDS: 40 and 600 spheres; image in global memory: 1300 and 5000) and the
     packed-FP32 scan (RTMI_SCAN=vector: geometry in LDS up to 560 spheres, in global memory beyond) are two
     filters in front of the same exact test: hit indices, accumulator bits and ray counts must be equal in
-    both builds, and equal from run to run."""
+    both builds, and equal from run to run.  The same holds for the order of the spheres on the device: the
+    library sorts them along a space-filling curve (RTMI_ORDER=caller keeps the caller's order); hits are
+    reported by the caller's index and equal distances (the scenes hold exact duplicates with different
+    materials) go to the lower caller's index either way."""
     import subprocess
     import sys
     from conftest import ROOT
     worker = os.path.join(ROOT, "tests", "scan_variant_worker.py")
     res = {}
-    for name, env in (("matrix", {}), ("vector", {"RTMI_SCAN": "vector"})):
+    for name, env in (("matrix", {}), ("vector", {"RTMI_SCAN": "vector"}), ("caller_order", {"RTMI_ORDER": "caller"}),
+                      ("vector_caller_order", {"RTMI_SCAN": "vector", "RTMI_ORDER": "caller"})):
         out = str(tmp_path / (name + ".npz"))
         r = subprocess.run([sys.executable, worker, out], env=dict(os.environ, **env), cwd=ROOT,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         res[name] = np.load(out)
     keys = sorted(res["matrix"].files)
-    assert keys == sorted(res["vector"].files) and len(keys) == 4 * 2 * 2 * 3
+    assert len(keys) == 4 * 2 * 2 * 3
+    for other in ("vector", "caller_order", "vector_caller_order"):
+        assert keys == sorted(res[other].files)
+        for k in keys:
+            a, b = res["matrix"][k], res[other][k]
+            assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
+                                  b.view(np.uint32) if b.dtype == np.float32 else b), (other, k)
     for k in keys:
-        a, b = res["matrix"][k], res["vector"][k]
-        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
-                              b.view(np.uint32) if b.dtype == np.float32 else b), k
         if "_0_" in k:                                   # first against second run of the same process
             k1 = k.replace("_0_", "_1_")
             assert np.array_equal(res["matrix"][k].tobytes(), res["matrix"][k1].tobytes()), k
