@@ -229,7 +229,7 @@ int resolve_chunk(int chunk_opt, uint32_t width, uint32_t height, int spp, bool 
 int scan_variant(const Ctx &g)
 {
     if (g.ntiles > 0 && !g_vector_scan)
-        return (g.ntiles <= kMaxTilesMatrix && mat_slots(g.n_pad, g.ntiles) >= kMatSlotsMin) ? kScanMatrix : kScanMatrixGlobal;
+        return (g.ntiles <= kMaxTilesMatrix && matrix_lds_bytes(g.n_pad, g.ntiles) <= (size_t)kLdsBytes) ? kScanMatrix : kScanMatrixGlobal;
     return g.n > kMaxSpheresLds ? kScanVectorGlobal : kScanVectorLds;
 }
 
@@ -373,7 +373,6 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             tp.orig = (const int32_t *)g.orig.p;
             tp.pairs = (const float *)g.pairs.p;
             tp.aimg = (const uint4 *)g.aimg.p; tp.ntiles = g.ntiles;
-            tp.mat_slots = scan_variant(g) == kScanMatrixGlobal ? mat_slots(0, 0) : mat_slots(g.n_pad, g.ntiles);
             tp.mat_scale = g.mat_scale; tp.mat_c_near = g.c_near * g.mat_scale;
             tp.n = g.n; tp.n_pad = g.n_pad;
             tp.nbig = g.nbig; memcpy(tp.big, g.big, sizeof tp.big); tp.c_near = g.c_near;

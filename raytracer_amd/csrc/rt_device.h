@@ -56,21 +56,26 @@ constexpr int queue_lds_bytes(int block_threads, int slots) { return (block_thre
 enum { kScanVectorLds = 0, kScanVectorGlobal = 1, kScanMatrix = 2, kScanMatrixGlobal = 3, kScanVariants = 4 };
 constexpr bool is_matrix(int variant) { return variant == kScanMatrix || variant == kScanMatrixGlobal; }
 constexpr int kTileSpheres = 32;
-constexpr int kMaxTilesMatrix = 35;        // sphere image 2 KB per tile (+ 0.5 KB of geometry): what leaves room for the queues
-constexpr int kMaxSpheresMatrix = kMaxTilesMatrix * kTileSpheres;
-constexpr int kMaxSpheresMatrixGlobal = 65504;   // queue entries are u16 sphere indices (rows of the last tile included)
+constexpr int kMaxSpheresMatrixGlobal = 65504;   // a candidate entry and a result key hold sphere indices in 16 bits
 constexpr int kMinSpheresMatrix = 32;      // smaller scenes: the vector scan (measured break-even 20-40 spheres)
 constexpr int kMatBlockThreads = RT_MAT_THREADS;   // one workgroup per CU: 4 waves per SIMD at 128 VGPRs
 constexpr int kLdsBytes = 160 * 1024;
-// candidate-queue slots (u16) per lane and ray half: what the LDS leaves next to the two images, at least
-// kMatSlotsMin (a half tile can add 16 entries to a queue: it is drained once a lane holds more than slots - 16)
-constexpr int kMatSlotsMin = 18, kMatSlotsMax = 32;
-inline int mat_slots(int n_pad, int ntiles)
+// Per-wave LDS region of the matrix scan: the wave's 64 rays (two float4 each), one result key per ray and the
+// wave's pooled candidate list.  Candidates are (ray, sphere) pairs appended by whichever lane saw them pass and
+// tested 64 at a time, one per lane, as soon as 64 are waiting: a half tile can add 32 x 32 = 1024 entries to
+// the at most 63 left over.
+constexpr int kMatRayBytes = 64 * 32, kMatKeyBytes = 64 * 8;
+constexpr int kMatListCap = 63 + 1024 + 1;
+constexpr int kMatWaveBytes = kMatRayBytes + kMatKeyBytes + kMatListCap * 4;
+static_assert(kMatWaveBytes % 16 == 0, "the wave regions stay 16-byte aligned");
+// LDS of the matrix scan with its images staged: [sphere image 2 KB per tile][geometry 16 B per sphere]
+// [caller's index 2 B per sphere][wave regions]
+inline size_t matrix_lds_bytes(int n_pad, int ntiles)
 {
-    const long room = (long)kLdsBytes - (long)ntiles * 128 * 16 - (long)n_pad * 16;
-    const long s = room / ((kMatBlockThreads / 64) * 2 * 64 * 2);
-    return (int)(s > kMatSlotsMax ? kMatSlotsMax : s);
+    return (size_t)ntiles * 128 * 16 + (size_t)n_pad * 16 + (size_t)n_pad * 2 + (size_t)(kMatBlockThreads / 64) * kMatWaveBytes;
 }
+constexpr int kMaxTilesMatrix = 20;        // what fits beside the wave regions of 16 waves (the host checks matrix_lds_bytes)
+constexpr int kMaxSpheresMatrix = kMaxTilesMatrix * kTileSpheres;
 constexpr int block_threads_of(int variant) { return is_matrix(variant) ? kMatBlockThreads : kBlockThreads; }
 constexpr int kMaxSpheresLds = 560;        // up to here the per-sphere records are staged in LDS: 7 workgroups of (9 KB + 14 KB of queues) still fit a CU
 constexpr int kMaxSpheres = 1 << 20;       // beyond kMaxSpheresLds they are read from global memory
@@ -91,7 +96,6 @@ struct TraceParams {
     float mat_scale;                       // power-of-two scale of the matrix scan's frame
     float mat_c_near;                      // max |C| over the filtered spheres, in that frame
     int ntiles;
-    int mat_slots;                         // queue slots per lane and ray half (matrix scan)
     int n, n_pad;
     int nbig;                              // spheres tested exactly for every ray
     int big[kMaxBig];
@@ -156,14 +160,12 @@ hipError_t prepare_trace_fast(LaunchCache &c, int mode, int variant, size_t lds_
 int trace_blocks_per_cu_strict(LaunchCache &c, int variant, size_t lds_bytes);
 int trace_blocks_per_cu_fast(LaunchCache &c, int variant, size_t lds_bytes);
 
-// Dynamic LDS of a trace kernel: [matrix image][geometry image][candidate queues].
+// Dynamic LDS of a trace kernel: [matrix image][geometry image][caller's indices][wave regions] (matrix scan),
+// [geometry image][candidate queues] (vector scan).
 inline size_t trace_lds_bytes(int variant, bool strict, int n_pad, int ntiles)
 {
-    if (variant == kScanMatrixGlobal)
-        return (size_t)(kMatBlockThreads / 64) * 2 * mat_slots(0, 0) * 64 * sizeof(uint16_t);
-    if (variant == kScanMatrix)
-        return (size_t)ntiles * 128 * sizeof(uint4) + (size_t)n_pad * sizeof(float4) +
-               (size_t)(kMatBlockThreads / 64) * 2 * mat_slots(n_pad, ntiles) * 64 * sizeof(uint16_t);
+    if (variant == kScanMatrixGlobal) return (size_t)(kMatBlockThreads / 64) * kMatWaveBytes;
+    if (variant == kScanMatrix) return matrix_lds_bytes(n_pad, ntiles);
     return (variant == kScanVectorGlobal ? 0 : (size_t)n_pad * sizeof(float4)) +
            (size_t)queue_lds_bytes(kBlockThreads, strict ? kQueueSlotsStrict : kQueueSlotsFast);
 }

@@ -218,40 +218,50 @@ __device__ __forceinline__ bool wins_tie(const Probe &q, int i)
     return q.hit >= 0 && q.orig[i] < q.orig[q.hit];
 }
 
-// hit_sphere (Main.c:625-672) for sphere i, up to the accept decision.
-__device__ __forceinline__ void exact_test_record(const float4 g, int i, Probe &q)
+// hit_sphere (Main.c:625-672) for the sphere record g = {C, r^2}: the root the reference would accept if nothing
+// nearer had been found yet.  Surrounds(root, tmin, closest) fails for the near root either because it is <= tmin,
+// and then the far root is tried, or because it is >= closest, and then the far root, which is not smaller, fails
+// too: the choice of root does not depend on closest.  a = |d|^2 (strict build; the fast build's d is a unit vector).
+__device__ __forceinline__ bool sphere_root(const float4 g, float ox, float oy, float oz, float dx, float dy, float dz,
+                                            float a, float tmin, float &t)
 {
-    const float ocx = g.x - q.ox, ocy = g.y - q.oy, ocz = g.z - q.oz;
+    const float ocx = g.x - ox, ocy = g.y - oy, ocz = g.z - oz;
 #if RT_STRICT
-    const float h = q.dx * ocx + q.dy * ocy + q.dz * ocz;
+    const float h = dx * ocx + dy * ocy + dz * ocz;
     const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - g.w;
-    const float disc = h * h - q.a * c;
-    if (!(disc < 0.0f)) {
-        const float sq = rt_sqrt(disc);
-        float root = (h - sq) / q.a;
-        // Surrounds(root, tmin, closest) fails for the near root either because it is <= tmin,
-        // and then the far root is tried, or because it is >= closest, and then the far root,
-        // which is not smaller, fails too: the choice of root does not depend on closest.
-        if (!(q.tmin < root)) root = (h + sq) / q.a;
-        if (q.tmin < root) {
-            if (root < q.closest) { q.closest = root; q.hit = i; }
-            else if (__builtin_expect(root == q.closest, 0)) { if (wins_tie(q, i)) q.hit = i; }
-        }
-    }
+    const float disc = h * h - a * c;
+    if (disc < 0.0f) return false;
+    const float sq = rt_sqrt(disc);
+    float root = (h - sq) / a;
+    if (!(tmin < root)) root = (h + sq) / a;
+    t = root;
+    return tmin < root;
 #else
-    const float h = fmaf(q.dz, ocz, fmaf(q.dy, ocy, q.dx * ocx));
+    (void)a;
+    const float h = fmaf(dz, ocz, fmaf(dy, ocy, dx * ocx));
     const float negc = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, g.w)));
     const float disc = fmaf(h, h, negc);
-    if (disc >= 0.0f) {
-        const float sq = rt_sqrt(disc);
-        const float t0 = h - sq;
-        const float t = (t0 > q.tmin) ? t0 : (h + sq);
-        if (t > q.tmin) {
-            if (t < q.closest) { q.closest = t; q.hit = i; }
-            else if (__builtin_expect(t == q.closest, 0)) { if (wins_tie(q, i)) q.hit = i; }
-        }
-    }
+    if (!(disc >= 0.0f)) return false;
+    const float sq = rt_sqrt(disc);
+    const float t0 = h - sq;
+    t = (t0 > tmin) ? t0 : (h + sq);
+    return t > tmin;
 #endif
+}
+
+// The accept decision of hit() for sphere i (device order) against the nearest hit found so far.
+__device__ __forceinline__ void exact_test_record(const float4 g, int i, Probe &q)
+{
+    float t;
+#if RT_STRICT
+    const float a = q.a;
+#else
+    const float a = 1.0f;
+#endif
+    if (sphere_root(g, q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, a, q.tmin, t)) {
+        if (t < q.closest) { q.closest = t; q.hit = i; }
+        else if (__builtin_expect(t == q.closest, 0)) { if (wins_tie(q, i)) q.hit = i; }
+    }
 }
 
 __device__ __forceinline__ void exact_test(const float4 *s_geom, int i, Probe &q)
@@ -387,53 +397,53 @@ __device__ __forceinline__ f16x8 as_frag(uint32_t a, uint32_t b, uint32_t c, uin
     return __builtin_bit_cast(f16x8, make_uint4(a, b, c, d));
 }
 
-// Exact test of the queued candidates of every lane's OWN ray.  An accumulator column is a ray and
-// the two halves of the wave hold different sphere rows of it, so the candidates of the ray of lane l
-// (half h = l >> 5) sit in queue h of lane l and in queue h of lane l ^ 32: queue[(h * slots + j) * 64 + lane].
-__device__ __forceinline__ void drain_matrix(const float4 *s_geom, const uint16_t *queue, int slots, int cnt0, int cnt1, int lane, Probe &q RT_DIAG_ARG)
+// The wave's LDS region of the matrix scan (rt_device.h): [64 rays x 2 float4][64 result keys][candidate list].
+struct WavePool {
+    float4 *rays;                   // rays[2 r] = {O, tmin}, rays[2 r + 1] = {d, |d|^2}
+    unsigned long long *keys;       // keys[r] = bits(t) << 32 | caller's index << 16 | device index of ray r's nearest hit so far
+    uint32_t *list;                 // ray << 16 | sphere (device order)
+};
+
+__device__ __forceinline__ WavePool wave_pool(char *base)
+{
+    WavePool w;
+    w.rays = reinterpret_cast<float4 *>(base);
+    w.keys = reinterpret_cast<unsigned long long *>(base + kMatRayBytes);
+    w.list = reinterpret_cast<uint32_t *>(base + kMatRayBytes + kMatKeyBytes);
+    return w;
+}
+
+// One dense step of exact tests: lane l takes entry first + l of the wave's candidate list (count <= 64 entries),
+// whichever ray it belongs to, reads that ray and the sphere and lowers the ray's key if the sphere is hit.
+// t > tmin > 0, so the bit patterns of t order like t; below t the key orders by the caller's index, which is
+// hit()'s rule for equal distances (the first sphere in the caller's list keeps the hit).
+__device__ __forceinline__ void drain_pooled(const float4 *s_geom, const uint16_t *s_orig16, const int32_t *orig, const WavePool &w,
+                                             int first, int count, int lane RT_DIAG_ARG)
 {
 #ifdef RT_DIAG
     const unsigned long long t0 = RT_STAMP();
+    dg.drain_iters++; dg.drain_lanes += (uint32_t)count;
 #endif
-    const int h = lane >> 5;
-    const auto c = __builtin_amdgcn_permlane32_swap((unsigned)cnt0, (unsigned)cnt1, false, false);
-    // c[0]: lanes < 32 keep their cnt0, lanes >= 32 get cnt1 of lane - 32;  c[1]: lanes < 32 get cnt0 of lane + 32
-    const int mine = h ? (int)c[1] : (int)c[0], theirs = h ? (int)c[0] : (int)c[1];
-    const int total = mine + theirs;
-    const uint16_t *qa = queue + h * (slots * 64);
-    // Entry j of the lane's ray: its own queue first, then the partner's.  An entry holds the tile's first
-    // sphere plus the accumulator's row offset; the half of the lane that queued it adds 4 (its rows are
-    // (i & 3) + 8 (i >> 2) + 4 (lane >> 5)).  Lanes beyond their last entry read slot 0 and test sphere 0
-    // into nothing (the index is replaced before it is used as an address).
-    auto sphere_of = [&](int j) {
-        const bool own = j < mine;
-        const int slot = own ? j : j - mine;
-        const int at = j < total ? slot * 64 + (own ? lane : (lane ^ 32)) : lane;
-        const int v = (int)qa[at] + (own ? 4 * h : 4 - 4 * h);
-        return j < total ? v : 0;
-    };
-    // Two LDS round trips per candidate (index, then record) would leave every step waiting: the index is
-    // read two steps ahead and the record one step ahead of the test.
-    int i0 = sphere_of(0);
-    int i1 = sphere_of(1);
-    float4 g0 = s_geom[i0];
-    for (int j = 0; __ballot(j < total) != 0ULL; j++) {
-#ifdef RT_DIAG
-        dg.drain_iters++; dg.drain_lanes += (uint32_t)__popcll(__ballot(j < total));
-#endif
-        const float4 g1 = s_geom[i1];
-        const int i2 = sphere_of(j + 2);
-        if (j < total) exact_test_record(g0, i0, q);
-        g0 = g1; i0 = i1; i1 = i2;
+    if (lane < count) {
+        const uint32_t e = w.list[first + lane];
+        const uint32_t ray = e >> 16, sph = e & 0xffffU;
+        const float4 r0 = w.rays[2 * ray], r1 = w.rays[2 * ray + 1];
+        const float4 g = s_geom[sph];
+        const uint32_t caller = s_orig16 != nullptr ? (uint32_t)s_orig16[sph] : (uint32_t)orig[sph];
+        float t;
+        if (sphere_root(g, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, r1.w, r0.w, t))
+            atomicMin(&w.keys[ray], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((caller << 16) | sph));
     }
 #ifdef RT_DIAG
     dg.t_drain += RT_STAMP() - t0;
 #endif
 }
 
-// One half tile: 16 accumulators per lane = 16 sphere rows of the column's ray.  The common case (no
-// sphere of the tile passes for any ray) costs eight maxima, one compare and one branch.
-__device__ __forceinline__ void queue_passes(const f32x16 &acc, int first, int lane, uint16_t *q, int &cnt, bool &appended RT_DIAG_ARG)
+// One half tile: 16 accumulators per lane = 16 sphere rows of the column's ray (row (i & 3) + 8 (i >> 2) +
+// 4 (lane >> 5) of the tile, ray 32 H + (lane & 31)).  The common case (no sphere of the tile passes for any
+// ray) costs eight maxima, one compare and one branch.  A pass appends (ray, sphere) to the wave's list at a
+// position taken from the ballot of the passing lanes; cnt is wave-uniform.  ebase = ray << 16 | 4 (lane >> 5).
+__device__ __forceinline__ void queue_passes(const f32x16 &acc, int first, uint32_t ebase, uint32_t *list, int &cnt RT_DIAG_ARG)
 {
     const float m0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
     const float m1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
@@ -444,19 +454,19 @@ __device__ __forceinline__ void queue_passes(const f32x16 &acc, int first, int l
     const float m6 = __builtin_fmaxf(__builtin_fmaxf(m2, m3), m4);
     const float mx = __builtin_fmaxf(m5, m6);
     if (__ballot(mx >= 0.0f) != 0ULL) {
-        appended = true;
 #ifdef RT_DIAG
         dg.branches++;
 #endif
         // the group maxima say where to look: five groups of three rows and the last row
         auto put = [&](int i) {
-            if (acc[i] >= 0.0f) {                            // row (i & 3) + 8 (i >> 2) (+ 4 (lane >> 5), added by the drain)
+            const bool pass = acc[i] >= 0.0f;
+            const unsigned long long m = __ballot(pass);
+            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)cnt));
+            if (pass) list[at] = ebase + (uint32_t)(first + (i & 3) + 8 * (i >> 2));
+            cnt += (int)__popcll(m);
 #ifdef RT_DIAG
-                dg.passes++;
+            dg.passes += (uint32_t)__popcll(m);
 #endif
-                q[cnt * 64 + lane] = (uint16_t)(first + (i & 3) + 8 * (i >> 2));
-                cnt++;
-            }
         };
         if (__ballot(m0 >= 0.0f) != 0ULL) { put(0); put(1); put(2); }
         if (__ballot(m1 >= 0.0f) != 0ULL) { put(3); put(4); put(5); }
@@ -479,9 +489,24 @@ __device__ __forceinline__ void queue_passes(const f32x16 &acc, int first, int l
 // for the rounding of the reference-order exact test that decides afterwards.  slack = 2^-17 S^2 (+ 0.01 for
 // f16 subnormal pieces) is twice the bound; measured over 16384 rays x all spheres of three scenes the
 // accumulator is within 2^-21.4 S^2 of the discriminant (tools/mfma_scan_proto.hip).
-__device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const float4 *s_geom, const uint4 *s_aimg, uint16_t *queue,
-                                                    int lane, float ux, float uy, float uz, Probe &q RT_DIAG_ARG)
+//
+// What passes the filter goes to the wave's pooled candidate list (LDS) and is tested exactly 64 entries at a
+// time, one per lane whichever ray an entry belongs to, as soon as 64 are waiting (drain_pooled): a ray's
+// candidates are few and unevenly spread over the lanes (about one per ray, up to five or six), so lane-private
+// queues kept four lanes in five idle during their exact tests.  Every lane publishes its ray in LDS before
+// the scan and reads the nearest hit from its ray's key afterwards.
+__device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const float4 *s_geom, const uint4 *s_aimg, const uint16_t *s_orig16,
+                                                    char *pool_base, int lane, float ux, float uy, float uz, Probe &q RT_DIAG_ARG)
 {
+    const WavePool w = wave_pool(pool_base);
+#if RT_STRICT
+    const float ray_a = q.a;
+#else
+    const float ray_a = 1.0f;
+#endif
+    w.rays[2 * lane] = make_float4(q.ox, q.oy, q.oz, q.tmin);
+    w.rays[2 * lane + 1] = make_float4(q.dx, q.dy, q.dz, ray_a);
+    w.keys[lane] = 0x7f7fffffffffffffULL;                    // max_f32, no sphere
 #ifdef RT_DIAG
     const unsigned long long tb0 = RT_STAMP();
 #endif
@@ -555,8 +580,14 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
             B[0][s2][v] = sw[0]; B[1][s2][v] = sw[1];
         }
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int slots = p.mat_slots;
-    int cnt0 = 0, cnt1 = 0;
+    int cnt = 0;                                             // entries waiting in the wave's list (wave-uniform)
+    const uint32_t ebase0 = ((uint32_t)(lane & 31) << 16) | (uint32_t)(4 * (lane >> 5)), ebase1 = ebase0 + (32U << 16);
+    auto drain_full_steps = [&]() {
+        while (cnt >= 64) {
+            cnt -= 64;
+            drain_pooled(s_geom, s_orig16, p.orig, w, cnt, 64, lane RT_DIAG_PASS);
+        }
+    };
     // Per tile: read the NEXT tile's fragments, issue this tile's four MFMAs (the two halves interleaved, so
     // that no instruction waits for the one before it), compare.  The order matters for correctness, not only
     // for speed.  A software-pipelined form of this loop, which issued the next tile's LDS reads right AFTER
@@ -578,15 +609,12 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[1], as_frag(B[0][1][0], B[0][1][1], B[0][1][2], B[0][1][3]), acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[1], as_frag(B[1][1][0], B[1][1][1], B[1][1][2], B[1][1][3]), acc1, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        bool appended = false;
-        queue_passes(acc0, t * kTileSpheres, lane, queue, cnt0, appended RT_DIAG_PASS);
-        queue_passes(acc1, t * kTileSpheres, lane, queue + slots * 64, cnt1, appended RT_DIAG_PASS);
+        // a half tile adds at most 1024 entries to the at most 63 that wait: kMatListCap
+        queue_passes(acc0, t * kTileSpheres, ebase0, w.list, cnt RT_DIAG_PASS);
+        drain_full_steps();
+        queue_passes(acc1, t * kTileSpheres, ebase1, w.list, cnt RT_DIAG_PASS);
+        drain_full_steps();
         __builtin_amdgcn_sched_barrier(0);
-        // a half tile adds at most 16 entries to a queue
-        if (appended && __ballot(cnt0 > slots - 16 || cnt1 > slots - 16) != 0ULL) {
-            drain_matrix(s_geom, queue, slots, cnt0, cnt1, lane, q RT_DIAG_PASS);
-            cnt0 = 0; cnt1 = 0;
-        }
     };
     f16x8 a[2], b[2];
     read_tile(a, 0);
@@ -601,7 +629,16 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
 #ifdef RT_DIAG
     dg.scans++;
 #endif
-    drain_matrix(s_geom, queue, slots, cnt0, cnt1, lane, q RT_DIAG_PASS);
+    if (cnt > 0) drain_pooled(s_geom, s_orig16, p.orig, w, 0, cnt, lane RT_DIAG_PASS);
+    // the lane's own ray: what the pooled tests found against what the big spheres gave
+    const unsigned long long key = w.keys[lane];
+    const uint32_t low = (uint32_t)key;
+    if (low != 0xffffffffU) {
+        const float t = __uint_as_float((uint32_t)(key >> 32));
+        const int sph = (int)(low & 0xffffU);
+        if (t < q.closest) { q.closest = t; q.hit = sph; }
+        else if (__builtin_expect(t == q.closest, 0)) { if (wins_tie(q, sph)) q.hit = sph; }
+    }
 }
 
 // hit() for a wave in which only a few lanes still carry a ray (the end of a launch): the 64
@@ -727,19 +764,22 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
     const float4 *s_geom, *s_matA, *s_matB;
     uint32_t *queue;
     const uint4 *s_aimg = nullptr;
-    uint16_t *queue16 = nullptr;
+    const uint16_t *s_orig16 = nullptr;
+    char *pool = nullptr;
     if (VARIANT == kScanMatrix) {
         uint4 *img = reinterpret_cast<uint4 *>(lds);                       // [ntiles][2][64]
         for (int i = threadIdx.x; i < p.ntiles * 128; i += blockDim.x) img[i] = p.aimg[i];
         float4 *gm = lds + p.ntiles * 128;                                 // [n_pad]
         for (int i = threadIdx.x; i < p.n_pad; i += blockDim.x) gm[i] = p.geom[i];
-        s_aimg = img; s_geom = gm;
+        uint16_t *o16 = reinterpret_cast<uint16_t *>(gm + p.n_pad);        // [n_pad] caller's indices (below 65536 here)
+        for (int i = threadIdx.x; i < p.n_pad; i += blockDim.x) o16[i] = (uint16_t)p.orig[i];
+        s_aimg = img; s_geom = gm; s_orig16 = o16;
         s_matA = p.matA; s_matB = p.matB;
-        queue16 = reinterpret_cast<uint16_t *>(gm + p.n_pad) + (threadIdx.x >> 6) * (2 * p.mat_slots * 64);
+        pool = reinterpret_cast<char *>(o16 + p.n_pad) + (threadIdx.x >> 6) * kMatWaveBytes;
         queue = nullptr;
     } else if (VARIANT == kScanMatrixGlobal) {
         s_aimg = p.aimg; s_geom = p.geom; s_matA = p.matA; s_matB = p.matB;
-        queue16 = reinterpret_cast<uint16_t *>(lds) + (threadIdx.x >> 6) * (2 * p.mat_slots * 64);
+        pool = reinterpret_cast<char *>(lds) + (threadIdx.x >> 6) * kMatWaveBytes;
         queue = nullptr;
     } else if (VARIANT == kScanVectorGlobal) {
         s_geom = p.geom; s_matA = p.matA; s_matB = p.matB;
@@ -887,7 +927,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
             const float inv = (q.a > 0.0f) ? __builtin_amdgcn_rsqf(q.a) : 0.0f;
             const unsigned long long live = __ballot(active);
             if (__popcll(live) <= p.coop_max) shared_ray_hit(p, s_geom, lane, live, q);
-            else if (is_matrix(VARIANT)) scan_spheres_matrix(p, s_geom, s_aimg, queue16, lane, q.dx * inv, q.dy * inv, q.dz * inv, q RT_DIAG_PASS);
+            else if (is_matrix(VARIANT)) scan_spheres_matrix(p, s_geom, s_aimg, s_orig16, pool, lane, q.dx * inv, q.dy * inv, q.dz * inv, q RT_DIAG_PASS);
             else scan_spheres(p, s_geom, queue, lane, q.dx * inv, q.dy * inv, q.dz * inv, 7.6293945e-6f, q RT_DIAG_PASS);
             if (!(q.a > 0.0f)) {
                 // a zero or NaN direction gives the filter nothing to work with: test everything
@@ -898,7 +938,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
 #else
         const unsigned long long live = __ballot(active);
         if (__popcll(live) <= p.coop_max) shared_ray_hit(p, s_geom, lane, live, q);
-        else if (is_matrix(VARIANT)) scan_spheres_matrix(p, s_geom, s_aimg, queue16, lane, q.dx, q.dy, q.dz, q RT_DIAG_PASS);
+        else if (is_matrix(VARIANT)) scan_spheres_matrix(p, s_geom, s_aimg, s_orig16, pool, lane, q.dx, q.dy, q.dz, q RT_DIAG_PASS);
         else scan_spheres(p, s_geom, queue, lane, q.dx, q.dy, q.dz, 1.9073486e-6f, q RT_DIAG_PASS);   // 2^-19
 #ifdef RT_DIAG
         if (__popcll(live) <= p.coop_max) dg.shared_rays += (uint32_t)__popcll(live); else dg.scan_lanes += (uint32_t)__popcll(live);
