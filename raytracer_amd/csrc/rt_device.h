@@ -60,13 +60,12 @@ constexpr int kMaxSpheresMatrixGlobal = 65504;   // a candidate entry and a resu
 constexpr int kMinSpheresMatrix = 32;      // smaller scenes: the vector scan (measured break-even 20-40 spheres)
 constexpr int kMatBlockThreads = RT_MAT_THREADS;   // one workgroup per CU: 4 waves per SIMD at 128 VGPRs
 constexpr int kLdsBytes = 160 * 1024;
-// Per-wave LDS region of the matrix scan: the wave's 64 rays (two float4 each), one result key per ray and the
-// wave's pooled candidate list.  Candidates are (ray, sphere) pairs appended by whichever lane saw them pass and
-// tested 64 at a time, one per lane, as soon as 64 are waiting: a half tile can add 32 x 32 = 1024 entries to
-// the at most 63 left over.
-constexpr int kMatRayBytes = 64 * 32, kMatKeyBytes = 64 * 8;
+// Per-wave LDS region of the matrix scan: one result key per ray and the wave's pooled candidate list.
+// Candidates are (ray, sphere) pairs appended by whichever lane saw them pass and tested 64 at a time, one per
+// lane, as soon as 64 are waiting: a half tile can add 32 x 32 = 1024 entries to the at most 63 left over.
+constexpr int kMatKeyBytes = 64 * 8;
 constexpr int kMatListCap = 63 + 1024 + 1;
-constexpr int kMatWaveBytes = kMatRayBytes + kMatKeyBytes + kMatListCap * 4;
+constexpr int kMatWaveBytes = kMatKeyBytes + kMatListCap * 4;
 static_assert(kMatWaveBytes % 16 == 0, "the wave regions stay 16-byte aligned");
 // LDS of the matrix scan with its images staged: [sphere image 2 KB per tile][geometry 16 B per sphere]
 // [caller's index 2 B per sphere][wave regions]
@@ -74,7 +73,7 @@ inline size_t matrix_lds_bytes(int n_pad, int ntiles)
 {
     return (size_t)ntiles * 128 * 16 + (size_t)n_pad * 16 + (size_t)n_pad * 2 + (size_t)(kMatBlockThreads / 64) * kMatWaveBytes;
 }
-constexpr int kMaxTilesMatrix = 20;        // what fits beside the wave regions of 16 waves (the host checks matrix_lds_bytes)
+constexpr int kMaxTilesMatrix = 32;        // what fits beside the wave regions of 16 waves (the host checks matrix_lds_bytes)
 constexpr int kMaxSpheresMatrix = kMaxTilesMatrix * kTileSpheres;
 constexpr int block_threads_of(int variant) { return is_matrix(variant) ? kMatBlockThreads : kBlockThreads; }
 constexpr int kMaxSpheresLds = 560;        // up to here the per-sphere records are staged in LDS: 7 workgroups of (9 KB + 14 KB of queues) still fit a CU

@@ -397,9 +397,8 @@ __device__ __forceinline__ f16x8 as_frag(uint32_t a, uint32_t b, uint32_t c, uin
     return __builtin_bit_cast(f16x8, make_uint4(a, b, c, d));
 }
 
-// The wave's LDS region of the matrix scan (rt_device.h): [64 rays x 2 float4][64 result keys][candidate list].
+// The wave's LDS region of the matrix scan (rt_device.h): [64 result keys][candidate list].
 struct WavePool {
-    float4 *rays;                   // rays[2 r] = {O, tmin}, rays[2 r + 1] = {d, |d|^2}
     unsigned long long *keys;       // keys[r] = bits(t) << 32 | caller's index << 16 | device index of ray r's nearest hit so far
     uint32_t *list;                 // ray << 16 | sphere (device order)
 };
@@ -407,31 +406,45 @@ struct WavePool {
 __device__ __forceinline__ WavePool wave_pool(char *base)
 {
     WavePool w;
-    w.rays = reinterpret_cast<float4 *>(base);
-    w.keys = reinterpret_cast<unsigned long long *>(base + kMatRayBytes);
-    w.list = reinterpret_cast<uint32_t *>(base + kMatRayBytes + kMatKeyBytes);
+    w.keys = reinterpret_cast<unsigned long long *>(base);
+    w.list = reinterpret_cast<uint32_t *>(base + kMatKeyBytes);
     return w;
 }
 
+__device__ __forceinline__ float lane_value(int byte_address, float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_address, __builtin_bit_cast(int, v)));
+}
+
 // One dense step of exact tests: lane l takes entry first + l of the wave's candidate list (count <= 64 entries),
-// whichever ray it belongs to, reads that ray and the sphere and lowers the ray's key if the sphere is hit.
-// t > tmin > 0, so the bit patterns of t order like t; below t the key orders by the caller's index, which is
-// hit()'s rule for equal distances (the first sphere in the caller's list keeps the hit).
+// whichever ray it belongs to, fetches that ray from the registers of the lane that owns it (all lanes take part
+// in the exchange: a lane outside the exec mask would supply zeros), reads the sphere and lowers the ray's key if
+// the sphere is hit.  t > tmin > 0, so the bit patterns of t order like t; below t the key orders by the caller's
+// index, which is hit()'s rule for equal distances (the first sphere in the caller's list keeps the hit).
 __device__ __forceinline__ void drain_pooled(const float4 *s_geom, const uint16_t *s_orig16, const int32_t *orig, const WavePool &w,
-                                             int first, int count, int lane RT_DIAG_ARG)
+                                             int first, int count, int lane, const Probe &q RT_DIAG_ARG)
 {
 #ifdef RT_DIAG
     const unsigned long long t0 = RT_STAMP();
     dg.drain_iters++; dg.drain_lanes += (uint32_t)count;
 #endif
-    if (lane < count) {
-        const uint32_t e = w.list[first + lane];
-        const uint32_t ray = e >> 16, sph = e & 0xffffU;
-        const float4 r0 = w.rays[2 * ray], r1 = w.rays[2 * ray + 1];
+    const bool mine = lane < count;
+    const uint32_t e = w.list[first + (mine ? lane : 0)];
+    const uint32_t ray = e >> 16, sph = e & 0xffffU;
+    const int from = (int)(ray << 2);
+    const float ox = lane_value(from, q.ox), oy = lane_value(from, q.oy), oz = lane_value(from, q.oz);
+    const float dx = lane_value(from, q.dx), dy = lane_value(from, q.dy), dz = lane_value(from, q.dz);
+    const float tmin = lane_value(from, q.tmin);
+#if RT_STRICT
+    const float a = lane_value(from, q.a);
+#else
+    const float a = 1.0f;
+#endif
+    if (mine) {
         const float4 g = s_geom[sph];
         const uint32_t caller = s_orig16 != nullptr ? (uint32_t)s_orig16[sph] : (uint32_t)orig[sph];
         float t;
-        if (sphere_root(g, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, r1.w, r0.w, t))
+        if (sphere_root(g, ox, oy, oz, dx, dy, dz, a, tmin, t))
             atomicMin(&w.keys[ray], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((caller << 16) | sph));
     }
 #ifdef RT_DIAG
@@ -493,19 +506,12 @@ __device__ __forceinline__ void queue_passes(const f32x16 &acc, int first, uint3
 // What passes the filter goes to the wave's pooled candidate list (LDS) and is tested exactly 64 entries at a
 // time, one per lane whichever ray an entry belongs to, as soon as 64 are waiting (drain_pooled): a ray's
 // candidates are few and unevenly spread over the lanes (about one per ray, up to five or six), so lane-private
-// queues kept four lanes in five idle during their exact tests.  Every lane publishes its ray in LDS before
-// the scan and reads the nearest hit from its ray's key afterwards.
+// queues kept four lanes in five idle during their exact tests.  A lane fetches the ray of its entry from the
+// registers of the lane that owns it and lowers that ray's key in LDS; every lane reads its own key afterwards.
 __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const float4 *s_geom, const uint4 *s_aimg, const uint16_t *s_orig16,
                                                     char *pool_base, int lane, float ux, float uy, float uz, Probe &q RT_DIAG_ARG)
 {
     const WavePool w = wave_pool(pool_base);
-#if RT_STRICT
-    const float ray_a = q.a;
-#else
-    const float ray_a = 1.0f;
-#endif
-    w.rays[2 * lane] = make_float4(q.ox, q.oy, q.oz, q.tmin);
-    w.rays[2 * lane + 1] = make_float4(q.dx, q.dy, q.dz, ray_a);
     w.keys[lane] = 0x7f7fffffffffffffULL;                    // max_f32, no sphere
 #ifdef RT_DIAG
     const unsigned long long tb0 = RT_STAMP();
@@ -585,7 +591,7 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
     auto drain_full_steps = [&]() {
         while (cnt >= 64) {
             cnt -= 64;
-            drain_pooled(s_geom, s_orig16, p.orig, w, cnt, 64, lane RT_DIAG_PASS);
+            drain_pooled(s_geom, s_orig16, p.orig, w, cnt, 64, lane, q RT_DIAG_PASS);
         }
     };
     // Per tile: read the NEXT tile's fragments, issue this tile's four MFMAs (the two halves interleaved, so
@@ -629,7 +635,7 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
 #ifdef RT_DIAG
     dg.scans++;
 #endif
-    if (cnt > 0) drain_pooled(s_geom, s_orig16, p.orig, w, 0, cnt, lane RT_DIAG_PASS);
+    if (cnt > 0) drain_pooled(s_geom, s_orig16, p.orig, w, 0, cnt, lane, q RT_DIAG_PASS);
     // the lane's own ray: what the pooled tests found against what the big spheres gave
     const unsigned long long key = w.keys[lane];
     const uint32_t low = (uint32_t)key;
