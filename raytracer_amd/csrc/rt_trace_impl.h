@@ -474,12 +474,14 @@ __device__ __forceinline__ void queue_passes(const f32x16 &acc, int first, uint3
         auto put = [&](int i) {
             const bool pass = acc[i] >= 0.0f;
             const unsigned long long m = __ballot(pass);
-            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)cnt));
-            if (pass) list[at] = ebase + (uint32_t)(first + (i & 3) + 8 * (i >> 2));
-            cnt += (int)__popcll(m);
+            if (m != 0ULL) {                                 // most rows of a group that holds a pass hold none
+                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)cnt));
+                if (pass) list[at] = ebase + (uint32_t)(first + (i & 3) + 8 * (i >> 2));
+                cnt += (int)__popcll(m);
 #ifdef RT_DIAG
-            dg.passes += (uint32_t)__popcll(m);
+                dg.passes += (uint32_t)__popcll(m);
 #endif
+            }
         };
         if (__ballot(m0 >= 0.0f) != 0ULL) { put(0); put(1); put(2); }
         if (__ballot(m1 >= 0.0f) != 0ULL) { put(3); put(4); put(5); }
