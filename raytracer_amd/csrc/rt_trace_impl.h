@@ -456,17 +456,25 @@ __device__ __forceinline__ void drain_pooled(const float4 *s_geom, const uint16_
 // 4 (lane >> 5) of the tile, ray 32 H + (lane & 31)).  The common case (no sphere of the tile passes for any
 // ray) costs eight maxima, one compare and one branch.  A pass appends (ray, sphere) to the wave's list at a
 // position taken from the ballot of the passing lanes; cnt is wave-uniform.  ebase = ray << 16 | 4 (lane >> 5).
-__device__ __forceinline__ void queue_passes(const f32x16 &acc, int first, uint32_t ebase, uint32_t *list, int &cnt RT_DIAG_ARG)
+struct RowMaxima { float g[5], all; };     // maxima of five groups of three rows (the sixteenth row goes into "all" only)
+
+__device__ __forceinline__ RowMaxima row_maxima(const f32x16 &acc)
 {
-    const float m0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
-    const float m1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
-    const float m2 = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]);
-    const float m3 = __builtin_fmaxf(__builtin_fmaxf(acc[9], acc[10]), acc[11]);
-    const float m4 = __builtin_fmaxf(__builtin_fmaxf(acc[12], acc[13]), acc[14]);
-    const float m5 = __builtin_fmaxf(__builtin_fmaxf(m0, m1), acc[15]);
-    const float m6 = __builtin_fmaxf(__builtin_fmaxf(m2, m3), m4);
-    const float mx = __builtin_fmaxf(m5, m6);
-    if (__ballot(mx >= 0.0f) != 0ULL) {
+    RowMaxima r;
+    r.g[0] = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
+    r.g[1] = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
+    r.g[2] = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]);
+    r.g[3] = __builtin_fmaxf(__builtin_fmaxf(acc[9], acc[10]), acc[11]);
+    r.g[4] = __builtin_fmaxf(__builtin_fmaxf(acc[12], acc[13]), acc[14]);
+    const float m5 = __builtin_fmaxf(__builtin_fmaxf(r.g[0], r.g[1]), acc[15]);
+    const float m6 = __builtin_fmaxf(__builtin_fmaxf(r.g[2], r.g[3]), r.g[4]);
+    r.all = __builtin_fmaxf(m5, m6);
+    return r;
+}
+
+__device__ __forceinline__ void queue_passes(const f32x16 &acc, const RowMaxima &rm, int first, uint32_t ebase, uint32_t *list, int &cnt RT_DIAG_ARG)
+{
+    if (__ballot(rm.all >= 0.0f) != 0ULL) {
 #ifdef RT_DIAG
         dg.branches++;
 #endif
@@ -483,11 +491,11 @@ __device__ __forceinline__ void queue_passes(const f32x16 &acc, int first, uint3
 #endif
             }
         };
-        if (__ballot(m0 >= 0.0f) != 0ULL) { put(0); put(1); put(2); }
-        if (__ballot(m1 >= 0.0f) != 0ULL) { put(3); put(4); put(5); }
-        if (__ballot(m2 >= 0.0f) != 0ULL) { put(6); put(7); put(8); }
-        if (__ballot(m3 >= 0.0f) != 0ULL) { put(9); put(10); put(11); }
-        if (__ballot(m4 >= 0.0f) != 0ULL) { put(12); put(13); put(14); }
+        if (__ballot(rm.g[0] >= 0.0f) != 0ULL) { put(0); put(1); put(2); }
+        if (__ballot(rm.g[1] >= 0.0f) != 0ULL) { put(3); put(4); put(5); }
+        if (__ballot(rm.g[2] >= 0.0f) != 0ULL) { put(6); put(7); put(8); }
+        if (__ballot(rm.g[3] >= 0.0f) != 0ULL) { put(9); put(10); put(11); }
+        if (__ballot(rm.g[4] >= 0.0f) != 0ULL) { put(12); put(13); put(14); }
         put(15);
     }
 }
@@ -618,10 +626,13 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[1], as_frag(B[1][1][0], B[1][1][1], B[1][1][2], B[1][1][3]), acc1, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         // a half tile adds at most 1024 entries to the at most 63 that wait: kMatListCap
-        queue_passes(acc0, t * kTileSpheres, ebase0, w.list, cnt RT_DIAG_PASS);
-        drain_full_steps();
-        queue_passes(acc1, t * kTileSpheres, ebase1, w.list, cnt RT_DIAG_PASS);
-        drain_full_steps();
+        const RowMaxima rm0 = row_maxima(acc0), rm1 = row_maxima(acc1);
+        if (__ballot(__builtin_fmaxf(rm0.all, rm1.all) >= 0.0f) != 0ULL) {       // two tiles in three hold no candidate at all
+            queue_passes(acc0, rm0, t * kTileSpheres, ebase0, w.list, cnt RT_DIAG_PASS);
+            drain_full_steps();
+            queue_passes(acc1, rm1, t * kTileSpheres, ebase1, w.list, cnt RT_DIAG_PASS);
+            drain_full_steps();
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
     f16x8 a[2], b[2];
