@@ -848,7 +848,7 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
     // Matrix scan: per 32-sphere tile the MFMA A fragments of the sphere features (rt_device.h), in a
     // frame scaled by a power of two that puts every filtered sphere within 120 of the origin (f16 range:
     // products of coordinates stay below 65504).  K entries of a sphere: feature f of (cx^2, cy^2, cz^2,
-    // cx cy, cx cz, cy cz, cx, cy, cz) at 3 f .. 3 f + 2 as (c1, c1, c2); 27, 28: 1, 1; 29, 30: the pieces
+    // 2 cx cy, 2 cx cz, 2 cy cz, 2 cx, 2 cy, 2 cz) at 3 f .. 3 f + 2 as (c1, c1, c2); 27, 28: 1, 1; 29, 30: the pieces
     // of k = |C|^2 - r^2; 31: 0.  Rows beyond the scene and the big spheres hold k = 65504 only: the ray's
     // constant is capped at 60000 (rt_trace_impl.h), so their accumulator stays below -5000.
     // Below kMinSpheresMatrix the packed-FP32 scan wins: the matrix scan pays about a hundred instructions per
@@ -867,8 +867,8 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
             if (i < n && !is_big[i]) {
                 const double cx = (double)spheres[i].center.x * mat_scale, cy = (double)spheres[i].center.y * mat_scale,
                              cz = (double)spheres[i].center.z * mat_scale, rr = (double)spheres[i].radius * mat_scale;
-                const float feat[9] = {(float)(cx * cx), (float)(cy * cy), (float)(cz * cz), (float)(cx * cy), (float)(cx * cz),
-                                       (float)(cy * cz), (float)cx, (float)cy, (float)cz};
+                const float feat[9] = {(float)(cx * cx), (float)(cy * cy), (float)(cz * cz), (float)(2.0 * cx * cy), (float)(2.0 * cx * cz),
+                                       (float)(2.0 * cy * cz), (float)(2.0 * cx), (float)(2.0 * cy), (float)(2.0 * cz)};
                 for (int f = 0; f < 9; f++) {
                     uint16_t pc[2];
                     split2(feat[f], pc);

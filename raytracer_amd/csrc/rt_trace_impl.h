@@ -548,42 +548,51 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
     const float px = fmaf(-g, ux, ox), py = fmaf(-g, uy, oy), pz = fmaf(-g, uz, oz);
     const float pp = fmaf(pz, pz, fmaf(py, py, px * px));
     const bool apart = !(pp <= 61504.0f);                                        // 248^2; also catches NaN
-    float feat[10];
+    float feat[10];                                    // the factors of two of the mixed and linear terms are on the sphere side
     feat[0] = ux * ux; feat[1] = uy * uy; feat[2] = uz * uz;
-    feat[3] = 2.0f * ux * uy; feat[4] = 2.0f * ux * uz; feat[5] = 2.0f * uy * uz;
-    feat[6] = 2.0f * px; feat[7] = 2.0f * py; feat[8] = 2.0f * pz;
+    feat[3] = ux * uy; feat[4] = ux * uz; feat[5] = uy * uz;
+    feat[6] = px; feat[7] = py; feat[8] = pz;
     feat[9] = fminf(slack - pp, 60000.0f);                                       // a slack beyond f16: everything passes
     if (apart) {
         // without the linear terms the sum is (u . C)^2 - |C|^2 + r^2 + constant <= r^2 + constant, r <= 120
         feat[6] = 0.0f; feat[7] = 0.0f; feat[8] = 0.0f;
         feat[9] = oo < 1e15f ? -20000.0f : 60000.0f;     // so far out that P itself is uncertain: everything passes
     }
-    _Float16 x1[10], x2[10];
 #pragma unroll
     for (int f = 0; f < 10; f++) {
         // The feature must be an f32 VALUE before it is split.  Left visible, the multiply that produced it is
-        // fused with the conversion into one mixed-precision FMA (one rounding, product -> f16) for the use in the
-        // subtraction, while the packed copy of x1 converts the rounded f32 (two roundings): the two x1 then
-        // differ by an f16 ulp now and then, and x1 + x2 misses the feature by 2^-11 of it.
+        // fused with the conversion into one mixed-precision FMA (one rounding, product -> f16) in one place and
+        // not in another: two x1 that differ by an f16 ulp now and then, and x1 + x2 misses the feature by 2^-11 of it.
         asm volatile("" : "+v"(feat[f]));
-        x1[f] = (_Float16)feat[f];
-        x2[f] = (_Float16)(feat[f] - (float)x1[f]);
     }
+    // The two f16 pieces of a feature, x1 = f16(x) and x2 = f16(x - x1): the difference is exact in f32, so the
+    // mixed-precision FMA that subtracts the f16 half of a register from x and writes the other half gives it in
+    // one instruction next to the x1 it was taken from.
+    auto pieces_lo_hi = [](float x) {                 // (x1, x2)
+        uint32_t r = pack_f16((_Float16)x, (_Float16)x);
+        asm("v_fma_mixhi_f16 %0, %1, 1.0, -%0 op_sel_hi:[0,0,1]" : "+v"(r) : "v"(x));
+        return r;
+    };
+    auto pieces_hi_lo = [](float x) {                 // (x2, x1)
+        uint32_t r = pack_f16((_Float16)x, (_Float16)x);
+        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(r) : "v"(x));
+        return r;
+    };
     // K entries of the lane's own ray, two per register.  Feature f (f < 9) at entries 3 f .. 3 f + 2 as
     // (x1, x2, x1) against the sphere side's (c1, c1, c2); entries 27, 28: the constant's pieces against
     // 1, 1; entries 29, 30: -1, -1 against the pieces of k; entry 31: 0.
-    const _Float16 m1 = (_Float16)-1.0f, z0 = (_Float16)0.0f;
     uint32_t R[16];
 #pragma unroll
     for (int k = 0; k < 4; k++) {                     // features 2 k and 2 k + 1 fill three registers
-        R[3 * k] = pack_f16(x1[2 * k], x2[2 * k]);
-        R[3 * k + 1] = pack_f16(x1[2 * k], x1[2 * k + 1]);
-        R[3 * k + 2] = pack_f16(x2[2 * k + 1], x1[2 * k + 1]);
+        R[3 * k] = pieces_lo_hi(feat[2 * k]);
+        R[3 * k + 1] = pack_f16((_Float16)feat[2 * k], (_Float16)feat[2 * k + 1]);
+        R[3 * k + 2] = pieces_hi_lo(feat[2 * k + 1]);
     }
-    R[12] = pack_f16(x1[8], x2[8]);
-    R[13] = pack_f16(x1[8], x1[9]);
-    R[14] = pack_f16(x2[9], m1);
-    R[15] = pack_f16(m1, z0);
+    R[12] = pieces_lo_hi(feat[8]);
+    R[13] = pack_f16((_Float16)feat[8], (_Float16)feat[9]);
+    R[14] = 0xbc000000U;                              // (x2 of the constant, -1)
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(R[14]) : "v"(feat[9]), "v"(R[13]));
+    R[15] = 0x0000bc00U;                              // (-1, 0)
     // B fragments: half H holds rays 32 H .. 32 H + 31 in its columns; lanes 0-31 supply K entries 0-7
     // of an instruction, lanes 32-63 entries 8-15, of the COLUMN's ray.  One half-swap per register
     // pair gives both halves' fragments.
