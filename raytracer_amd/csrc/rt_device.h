@@ -45,14 +45,15 @@ constexpr int queue_lds_bytes(int block_threads, int slots) { return (block_thre
 //                     by a power of two (spheres within 120 of the origin) each f32 feature is split into
 //                     two f16 pieces x = x1 + x2 and the products x1 y1 + x1 y2 + x2 y1 are summed by
 //                     v_mfma_f32_32x32x16_f16 in f32 (K = 9 x 3 + 2 + 2 = 31 of 32): 32 spheres x 32 rays
-//                     per 2 instructions; the vector ALU only compares the accumulators with zero.
+//                     per 2 instructions; the vector ALU only compares the accumulators with zero and writes what
+//                     passes into the wave's pooled candidate list (exact tests 64 candidates at a time).
 //                     aimg[tile][s][lane] holds the sphere side as MFMA A fragments (lane l: sphere
 //                     32 tile + (l & 31), K entries 16 s + 8 (l >> 5) ..+7).
 //   kScanVectorLds    packed-FP32 vector scan, per-sphere records in LDS (selectable for comparison)
 //   kScanVectorGlobal packed-FP32 vector scan, per-sphere records from global memory (larger scenes)
 //   kScanMatrixGlobal the matrix scan for scenes whose image does not fit the LDS: the fragments come from
 //                     global memory (L1 / L2: every wave of the chip reads the same tiles), one tile ahead of
-//                     their use, and so do the per-sphere records of the exact test; the LDS holds the queues
+//                     their use, and so do the per-sphere records of the exact test; the LDS holds the wave regions
 enum { kScanVectorLds = 0, kScanVectorGlobal = 1, kScanMatrix = 2, kScanMatrixGlobal = 3, kScanVariants = 4 };
 constexpr bool is_matrix(int variant) { return variant == kScanMatrix || variant == kScanMatrixGlobal; }
 constexpr int kTileSpheres = 32;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Final evidence of the round under gpurun_out/r2b/ (copied into profiles/r2b_final/ afterwards).
+# Evidence of a round under gpurun_out/<name>/ (copied into profiles/<name>_final/ afterwards):  bash tools/evidence_round.sh <name>
 set -o pipefail
 R=$PWD
 N=${1:-r2c}
