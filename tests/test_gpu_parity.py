@@ -492,6 +492,39 @@ def test_strict_build_matches_checker_on_random_scenes(rt, n, seed):
         assert (r["hit"] >= 0).mean() > 0.2                  # the view does see the scene
 
 
+@pytest.mark.parametrize("n", [64, 96, 1056])
+def test_every_sphere_is_a_candidate_for_every_ray(rt, n):
+    """The eye sits inside n equal spheres whose centres lie close together: every ray passes the filter for
+    every sphere, so each half tile of the matrix scan appends its full 32 x 32 entries to the wave's candidate
+    list (the case its capacity is sized for), with the sphere image in LDS (64, 96) and in global memory (1056).
+    Strict build against the checker, bit for bit; the fast build must see the same first hits."""
+    r = np.random.default_rng(77)
+    sph = np.zeros(n, dtype=rc.SPHERE_DTYPE)
+    sph["center"] = r.uniform(-0.5, 0.5, (n, 3))
+    sph["radius"] = r.uniform(4.0, 6.0, n)
+    sph["mat_type"] = r.integers(0, 3, n)
+    sph["albedo"] = r.uniform(0.3, 0.9, (n, 3))
+    sph["fuzz"] = r.uniform(0, 0.3, n)
+    sph["ior"] = 1.5
+    rt.set_world(sph)
+    p = rt.default_params()
+    p.pos = rt.Vec3(0.1, 0.0, -0.1)
+    p.target = rt.Vec3(3.0, 0.5, 1.0)
+    p.vfov = 100.0
+    W, H = 96, 54
+    cam = rt.camera(W, H, p)
+    ccam = rc.Camera.from_buffer_copy(bytes(cam))
+    g = rt.render(cam, W, H, 2, 6, strict_fp=True, seed=3, chunk_spp=1, want_hit=True, want_accum=True)
+    c = rc.render(ccam, sph, W, H, 2, 6, rng=rc.RNG_COUNTER, seed=3, chunk_spp=1, want_hit=True, want_accum=True)
+    assert (c["hit"] >= 0).all()
+    assert np.array_equal(g["hit"], c["hit"])
+    assert np.array_equal(g["accum"].view(np.uint32), c["accum"].view(np.uint32))
+    assert int(g["stats"].rays) == int(c["stats"].rays)
+    f = rt.render(cam, W, H, 2, 1, mode=rt.MODE_CONST_U, seed=3, chunk_spp=1, want_hit=True)
+    s1 = rt.render(cam, W, H, 2, 1, mode=rt.MODE_CONST_U, strict_fp=True, seed=3, chunk_spp=1, want_hit=True)
+    assert (f["hit"] != s1["hit"]).mean() < 2e-3
+
+
 @pytest.mark.parametrize("W,H,spp,depth", [(1, 1, 1, 1), (3, 2, 2, 3), (65, 1, 3, 50), (1, 70, 5, 2), (257, 3, 1, 50)])
 def test_odd_image_sizes_match_checker(rt, W, H, spp, depth):
     """Images smaller than a wave, a workgroup or a unit pool, in both summation modes."""
