@@ -376,10 +376,15 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             tp.mat_scale = g.mat_scale; tp.mat_c_near = g.c_near * g.mat_scale;
             tp.n = g.n; tp.n_pad = g.n_pad;
             tp.nbig = g.nbig; memcpy(tp.big, g.big, sizeof tp.big); tp.c_near = g.c_near;
-            // one ray over all spheres costs about 9 vector instructions per sphere pair in the scan (for
-            // all 64 lanes at once) and about 26 per 64 spheres plus a 6-step reduction when the
-            // lanes share one ray: the shared form wins while few rays are left in the wave
-            tp.coop_max = std::min(16, (int)((g.n_pad / 2 * 9 + 200) / (((g.n + 63) / 64) * 26 + 60)));
+            // one ray over all spheres costs about 9 vector instructions per sphere pair in the packed-FP32
+            // scan (for all 64 lanes at once) and about 26 per 64 spheres plus a 6-step reduction when the
+            // lanes share one ray: the shared form wins while few rays are left in the wave.  The matrix scan
+            // costs a wave about 54 instruction times per 32-sphere tile (its matrix instructions included) plus
+            // 150 for the ray features: break-even at 4 rays whatever the scene size (measured on the 488-sphere
+            // scene, 1920x1080 at 1 spp per frame: 800 / 809 / 783 / 757 frames/s at 2 / 4 / 6 / 8 rays).
+            const int shared_cost = ((g.n + 63) / 64) * 26 + 60;
+            if (is_matrix(scan_variant(g))) tp.coop_max = std::max(2, std::min(16, (150 + g.ntiles * 54 + shared_cost / 2) / shared_cost));
+            else tp.coop_max = std::min(16, (g.n_pad / 2 * 9 + 200) / shared_cost);
             tp.width = width; tp.height = height; tp.npix = npix;
             tp.tile_rows = tile_rows; tp.part_index = part_index; tp.part_count = part_count;
             tp.rows = nullptr;
