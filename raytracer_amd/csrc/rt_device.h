@@ -106,6 +106,7 @@ struct TraceParams {
     int tile_rows, part_index, part_count; // owned row k -> image row, see part_row_at()
     const uint32_t *rows;                  // or, if not null, rows[k] (explicit partition)
     int spp, chunk_spp, nchunks, max_depth;
+    int pool_units;                        // work units a wave takes from the global counter at a time
     int mode;                              // RT_MODE_*
     uint32_t seed, sample_base;
     float4 *partial;                       // [nchunks][npix] per-chunk colour sums

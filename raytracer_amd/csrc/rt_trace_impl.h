@@ -23,9 +23,6 @@
 #error "RT_STRICT must be defined"
 #endif
 
-#ifndef RT_POOL_UNITS
-#define RT_POOL_UNITS 64
-#endif
 
 namespace rtmi {
 namespace RT_NS {
@@ -290,7 +287,6 @@ struct Diag {
 #endif
 
 constexpr int kQueueSlots = RT_STRICT ? kQueueSlotsStrict : kQueueSlotsFast;   // per lane
-constexpr int kPoolUnits = RT_POOL_UNITS;  // work units a wave takes from the global counter at a time
 constexpr int kPairBatch = 4;              // pairs between two queue-overflow checks
 static_assert(kQueueSlots > 2 * kPairBatch, "a batch of pairs must fit the queue");
 static_assert(kGeomPad == 2 * kPairBatch, "the sphere list is padded to whole batches");
@@ -840,10 +836,11 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
     bool need_sample = true;   // lane must start a new sample
     uint32_t rays = 0;
     const uint32_t waves_per_block = blockDim.x >> 6;
-    const unsigned long long static_units = (unsigned long long)gridDim.x * waves_per_block * kPoolUnits;
-    const unsigned long long first = (unsigned long long)(blockIdx.x * waves_per_block + (threadIdx.x >> 6)) * kPoolUnits;
+    const uint32_t pool_units = (uint32_t)p.pool_units;    // work units a wave takes from the global counter at a time
+    const unsigned long long static_units = (unsigned long long)gridDim.x * waves_per_block * pool_units;
+    const unsigned long long first = (unsigned long long)(blockIdx.x * waves_per_block + (threadIdx.x >> 6)) * pool_units;
     uint32_t pool_next = first < total ? (uint32_t)first : total;
-    uint32_t pool_end = first + kPoolUnits < total ? (uint32_t)(first + kPoolUnits) : total;
+    uint32_t pool_end = first + pool_units < total ? (uint32_t)(first + pool_units) : total;
     pool_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_next);       // wave-uniform by construction
     pool_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_end);
 #ifdef RT_DIAG
@@ -853,7 +850,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
 
     for (;;) {
         // ---- pull work units ----------------------------------------------------------
-        // The wave keeps a pool of kPoolUnits consecutive units (wave-uniform registers) and
+        // The wave keeps a pool of pool_units consecutive units (wave-uniform registers) and
         // hands them to the lanes that finished one; the one global counter is touched once
         // per pool, not once per hand-out (thousands of waves on one address saturate the atomic
         // unit).  The first pool of every wave is static (units wave*64 ...), so a launch does
@@ -865,7 +862,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
         while (want != 0ULL) {
             if (pool_next == pool_end) {
                 unsigned long long b64 = 0;
-                if (lane == 0) b64 = atomicAdd(&p.counters[0], (unsigned long long)kPoolUnits) + static_units;
+                if (lane == 0) b64 = atomicAdd(&p.counters[0], (unsigned long long)pool_units) + static_units;
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64);
                 const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b64 >> 32));
                 if (hi != 0U || lo >= total) {              // no units left: the waiting lanes retire
@@ -874,7 +871,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
                     break;
                 }
                 pool_next = lo;
-                pool_end = (total - lo < (uint32_t)kPoolUnits) ? total : lo + (uint32_t)kPoolUnits;
+                pool_end = (total - lo < pool_units) ? total : lo + pool_units;
             }
             const uint32_t avail = pool_end - pool_next;
             const uint32_t asked = (uint32_t)__popcll(want);
