@@ -8,7 +8,7 @@
 // Mapping: one lane = one stream of pixel samples.  A lane owns a work unit (pixel, chunk of
 // samples), traces its samples one after another, and immediately starts the next sample when a
 // path ends, so that every lane of the wave has a live ray whenever the wave enters the sphere
-// loop.  Lanes that run out of samples take the next unit from their wave's pool of 64 units
+// loop.  Lanes that run out of samples take the next unit from their wave's pool of 64 to 512 units
 // (one ballot and a prefix count); a wave refills its pool from a global counter with one atomic.
 // A wave with only a few rays left tests each of them with all 64 lanes (shared_ray_hit).
 //
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
         // The wave keeps a pool of pool_units consecutive units (wave-uniform registers) and
         // hands them to the lanes that finished one; the one global counter is touched once
         // per pool, not once per hand-out (thousands of waves on one address saturate the atomic
-        // unit).  The first pool of every wave is static (units wave*64 ...), so a launch does
+        // unit).  The first pool of every wave is static (units wave * pool_units ...), so a launch does
         // not open with one atomic per wave either; the counter hands out what lies beyond.
 #ifdef RT_DIAG
         const unsigned long long ts0 = RT_STAMP();
