@@ -758,8 +758,8 @@ static uint32_t morton3(uint32_t x, uint32_t y, uint32_t z)
     return spread(x) | (spread(y) << 1) | (spread(z) << 2);
 }
 
-// Device order of the spheres: along the Z-order curve through their centres (cubic cells over the bounding box
-// of the finite centres; equal cells keep the caller's order), so that the 32 spheres of a tile of the matrix scan
+// Device order of the spheres: along the Z-order curve through their centres (cubic cells over the bulk of the
+// finite centres; equal cells keep the caller's order), so that the 32 spheres of a tile of the matrix scan
 // are neighbours in space.  The rays of a wave start near each other, and what they pass then sits in few tiles:
 // the appends, which cost per half tile that holds a candidate, fell by a quarter on the 488-sphere scene (4 % of
 // the kernel time; a shuffled list ran 6 % slower than the caller's order, which was sorted by one coordinate).
@@ -769,20 +769,29 @@ static std::vector<int32_t> device_order(const rt_sphere *spheres, int n)
 {
     std::vector<int32_t> order(n);
     for (int i = 0; i < n; i++) order[i] = i;
+    // the grid spans the 2 % .. 98 % quantiles of each coordinate (cells beyond are clamped): one far-away or huge
+    // sphere (a ground of radius 1000 centred 1000 below) must not blow the cells up until the rest shares one
+    auto coord = [&](int i, int a) { return (double)(a == 0 ? spheres[i].center.x : a == 1 ? spheres[i].center.y : spheres[i].center.z); };
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     bool any = false;
-    auto coord = [&](int i, int a) { return (double)(a == 0 ? spheres[i].center.x : a == 1 ? spheres[i].center.y : spheres[i].center.z); };
-    for (int i = 0; i < n; i++) {
-        if (!(std::isfinite(coord(i, 0)) && std::isfinite(coord(i, 1)) && std::isfinite(coord(i, 2)))) continue;
-        for (int a = 0; a < 3; a++) {
-            const double c = coord(i, a);
-            if (!any || c < lo[a]) lo[a] = c;
-            if (!any || c > hi[a]) hi[a] = c;
-        }
+    std::vector<double> v;
+    v.reserve(n);
+    for (int a = 0; a < 3; a++) {
+        v.clear();
+        for (int i = 0; i < n; i++)
+            if (std::isfinite(coord(i, 0)) && std::isfinite(coord(i, 1)) && std::isfinite(coord(i, 2))) v.push_back(coord(i, a));
+        if (v.empty()) break;
         any = true;
+        std::sort(v.begin(), v.end());
+        lo[a] = v[(size_t)(0.02 * (double)(v.size() - 1))];
+        hi[a] = v[(size_t)(0.98 * (double)(v.size() - 1) + 0.999)];
+        if (!(hi[a] > lo[a])) { lo[a] = v.front(); hi[a] = v.back(); }
     }
     const double span = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
     if (!any || !(span > 0.0) || !std::isfinite(span)) return order;
+    // fine cells: with 8 to 32 cells per axis the spheres of a cell stay in the caller's order and the 488-sphere
+    // scene ran 4 % slower (239.5 against 230.4 ms); 64 cells: 234.2 ms
+    const double cells = 1024.0;
     std::vector<uint32_t> key(n, 0xffffffffU);
     for (int i = 0; i < n; i++) {
         uint32_t cell[3];
@@ -790,8 +799,8 @@ static std::vector<int32_t> device_order(const rt_sphere *spheres, int n)
         for (int a = 0; a < 3; a++) {
             const double c = coord(i, a);
             if (!std::isfinite(c)) { ok = false; break; }
-            const double q = (c - lo[a]) / span * 1023.0;
-            cell[a] = (uint32_t)std::min(1023.0, std::max(0.0, q));
+            const double q = (c - lo[a]) / span * cells;
+            cell[a] = (uint32_t)std::min(cells - 1.0, std::max(0.0, q));
         }
         if (ok) key[i] = morton3(cell[0], cell[1], cell[2]);
     }
