@@ -891,7 +891,10 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
     std::vector<uint16_t> aimg((size_t)ntiles * 2 * 64 * 8, 0);
     for (int t = 0; t < ntiles; t++)
         for (int row = 0; row < kTileSpheres; row++) {
-            const int i = t * kTileSpheres + row;
+            // accumulator a of a lane in wave half h is tile row (a & 3) + 8 (a >> 2) + 4 h: that row holds sphere
+            // 2 a + h of the tile, so that the three accumulators of a group of the compare tree cover six
+            // consecutive spheres (neighbours in space) and a ray's candidates turn up in few groups
+            const int i = t * kTileSpheres + 2 * ((row & 3) | ((row >> 3) << 2)) + ((row >> 2) & 1);
             uint16_t ent[32];
             memset(ent, 0, sizeof ent);
             if (i < n && !is_big[i]) {

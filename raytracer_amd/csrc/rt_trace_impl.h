@@ -448,10 +448,11 @@ __device__ __forceinline__ void drain_pooled(const float4 *s_geom, const uint16_
 #endif
 }
 
-// One half tile: 16 accumulators per lane = 16 sphere rows of the column's ray (row (i & 3) + 8 (i >> 2) +
-// 4 (lane >> 5) of the tile, ray 32 H + (lane & 31)).  The common case (no sphere of the tile passes for any
-// ray) costs eight maxima, one compare and one branch.  A pass appends (ray, sphere) to the wave's list at a
-// position taken from the ballot of the passing lanes; cnt is wave-uniform.  ebase = ray << 16 | 4 (lane >> 5).
+// One half tile: 16 accumulators per lane = 16 spheres of the tile against the column's ray (accumulator i of a
+// lane in wave half h is tile row (i & 3) + 8 (i >> 2) + 4 h, where the image keeps sphere 2 i + h of the tile;
+// ray 32 H + (lane & 31)).  The common case (no sphere of the tile passes for any ray) costs eight maxima, one
+// compare and one branch.  A pass appends (ray, sphere) to the wave's list at a position taken from the ballot of
+// the passing lanes; cnt is wave-uniform.  ebase = ray << 16 | (lane >> 5).
 struct RowMaxima { float g[5], all; };     // maxima of five groups of three rows (the sixteenth row goes into "all" only)
 
 __device__ __forceinline__ RowMaxima row_maxima(const f32x16 &acc)
@@ -480,7 +481,7 @@ __device__ __forceinline__ void queue_passes(const f32x16 &acc, const RowMaxima 
             const unsigned long long m = __ballot(pass);
             if (m != 0ULL) {                                 // most rows of a group that holds a pass hold none
                 const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)cnt));
-                if (pass) list[at] = ebase + (uint32_t)(first + (i & 3) + 8 * (i >> 2));
+                if (pass) list[at] = ebase + (uint32_t)(first + 2 * i);
                 cnt += (int)__popcll(m);
 #ifdef RT_DIAG
                 dg.passes += (uint32_t)__popcll(m);
@@ -602,7 +603,7 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
         }
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int cnt = 0;                                             // entries waiting in the wave's list (wave-uniform)
-    const uint32_t ebase0 = ((uint32_t)(lane & 31) << 16) | (uint32_t)(4 * (lane >> 5)), ebase1 = ebase0 + (32U << 16);
+    const uint32_t ebase0 = ((uint32_t)(lane & 31) << 16) | (uint32_t)(lane >> 5), ebase1 = ebase0 + (32U << 16);
     auto drain_full_steps = [&]() {
         while (cnt >= 64) {
             cnt -= 64;
