@@ -22,9 +22,16 @@ def main():
     L.rt_diag_counters.restype = None
     L.rt_diag_counters.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
     rt.init(0)
-    cases = [("sf", None)] + [(k, k) for k in ss.VIEWS]
+    cases = [("sf", None)] + [(k, k) for k in ss.VIEWS] + [("gen127", "gen"), ("gen130", "gen")]
     for name, kind in cases:
-        if kind is None:
+        if kind == "gen":
+            # the generated scene at both ends of the switch from the matrix scan (at most 65504 spheres, image in
+            # global memory) to the packed-FP32 scan: 64517 and 67601 spheres
+            sph = rt.scene_generate(int(name[3:]), 0)
+            W, H, spp, depth = 192, 108, 2, 8
+            cam = rt.camera(W, H)
+            kind = None
+        elif kind is None:
             sph = np.fromfile(os.path.join(ROOT, "tests", "golden", "scene_sf.bin"), dtype=rt.SPHERE_DTYPE)
             W, H, spp, depth = 400, 225, 8, 50
             cam = rt.camera(W, H)

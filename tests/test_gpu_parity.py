@@ -280,7 +280,7 @@ def test_filter_and_drain_equal_brute_force(rt):
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     rows = [json.loads(l) for l in res.stdout.decode().splitlines() if l.startswith("{")]
-    assert len(rows) == (1 + len(ss.VIEWS)) * 4
+    assert len(rows) == (3 + len(ss.VIEWS)) * 4          # final scene, stress views, two generated scenes of 65 000 spheres
     for row in rows:
         print(row)
         assert row["rays"] > 0 and row["lost_hits"] == 0, row
