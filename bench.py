@@ -118,8 +118,30 @@ def measured_traffic(kernel_substr, workload_key):
             tot[name] = scale * sum(vals) / len(vals)
         if tot:
             best = {"bytes": tot["WRITE_SIZE"] + tot["FETCH_SIZE"], "write": tot["WRITE_SIZE"], "fetch": tot["FETCH_SIZE"],
-                    "source": os.path.relpath(d, ROOT)}
+                    "source": os.path.relpath(d, ROOT), "busy": measured_busy(d, kernel_substr)}
     return best
+
+
+def measured_busy(d, kernel_substr):
+    """Occupation of the two pipes the kernel issues to, from the SQ counter passes of the same profile directory:
+    vector ALU = 4 x SQ_ACTIVE_INST_VALU (quad-cycles) and matrix cores = SQ_VALU_MFMA_BUSY_CYCLES, both over
+    GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs; lanes = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU).  None if absent."""
+    val = {}
+    for name in ("pmc_a.csv", "pmc_b.csv"):
+        path = os.path.join(d, name)
+        if not os.path.exists(path):
+            return None
+        for r in csv.DictReader(open(path)):
+            if kernel_substr in r["Kernel_Name"]:
+                val[r["Counter_Name"]] = val.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    try:
+        simd_cycles = val["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+        return {"valu_issue": round(4.0 * val["SQ_ACTIVE_INST_VALU"] / simd_cycles, 3),
+                "mfma": round(val["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles, 3),
+                "lanes": round(val["SQ_THREAD_CYCLES_VALU"] / (64.0 * val["SQ_ACTIVE_INST_VALU"]), 3),
+                "vector_instructions_per_launch": val["SQ_INSTS_VALU"] - val.get("SQ_INSTS_MFMA", 0.0)}
+    except (KeyError, ZeroDivisionError):
+        return None
 
 
 class MockRt:
@@ -357,6 +379,9 @@ def main():
                                     "numerator": "executed matrix flop (62 per ray-sphere test: 31 f16 products + sums) / kernel time"},
                          "traffic": round(traffic["bytes"]) if traffic else None,
                          "traffic_source": traffic["source"] if traffic else None,
+                         # what binds the kernel: the share of the time its vector-ALU issue port (the binding one)
+                         # and its matrix pipe were occupied, from the same committed counter passes
+                         "busy": traffic["busy"] if traffic else None,
                          "kernel": "trace_kernel", "kernel_ms": round(kernel_ms, 3),
                          "flop_per_sphere_test": FLOP_PER_TEST,
                          "sphere_tests_per_launch": tests, "rays_per_sample": round(rays_all / samples_all, 4)},
