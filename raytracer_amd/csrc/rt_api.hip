@@ -888,7 +888,7 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
     for (int i = 0; i < n; i++) if (!is_big[i]) reach = std::max(reach, extent[i]);
     float mat_scale = 1.0f;
     if (reach > 0.0) mat_scale = (float)std::exp2(std::min(100.0, std::max(-100.0, std::floor(std::log2(120.0 / reach)))));
-    std::vector<uint16_t> aimg((size_t)ntiles * 2 * 64 * 8, 0);
+    std::vector<uint16_t> aimg((size_t)(ntiles + 1) * 2 * 64 * 8, 0);      // one spare tile: the scan reads one tile ahead
     for (int t = 0; t < ntiles; t++)
         for (int row = 0; row < kTileSpheres; row++) {
             // accumulator a of a lane in wave half h is tile row (a & 3) + 8 (a >> 2) + 4 h: that row holds sphere

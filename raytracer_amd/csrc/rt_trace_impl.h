@@ -619,10 +619,11 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
     // reads are issued BEFORE the MFMAs, into a buffer of their own (two buffers used in turn), and every
     // register an MFMA reads stays untouched until its accumulators have been read, which waits for the
     // instruction to finish; no MFMA is in flight when the scan ends.  This form is deterministic.
-    auto read_tile = [&](f16x8 (&x)[2], int t) {
-        const int tc = t < p.ntiles ? t : p.ntiles - 1;
+    // (the read one tile ahead goes one tile beyond the image at the end of the scan: in LDS that is the geometry
+    // and the wave regions behind the image, in global memory a spare tile the host allocates; it is never used)
+    auto read_tile = [&](f16x8 (&x)[2], const uint4 *tile) {              // tile: the lane's entry of the tile's first fragment
 #pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) x[s2] = __builtin_bit_cast(f16x8, s_aimg[(tc * 2 + s2) * 64 + lane]);
+        for (int s2 = 0; s2 < 2; s2++) x[s2] = __builtin_bit_cast(f16x8, tile[s2 * 64]);
         __builtin_amdgcn_sched_barrier(0);
     };
     auto do_tile = [&](const f16x8 (&x)[2], int t) {
@@ -642,12 +643,13 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
         __builtin_amdgcn_sched_barrier(0);
     };
     f16x8 a[2], b[2];
-    read_tile(a, 0);
-    for (int t = 0; t < p.ntiles; t += 2) {
-        read_tile(b, t + 1);
+    const uint4 *tile = s_aimg + lane;                 // one address register stepped per pair of tiles, constant offsets from it
+    read_tile(a, tile);
+    for (int t = 0; t < p.ntiles; t += 2, tile += 256) {
+        read_tile(b, tile + 128);
         do_tile(a, t);
         if (t + 1 < p.ntiles) {
-            read_tile(a, t + 2);
+            read_tile(a, tile + 256);
             do_tile(b, t + 1);
         }
     }
