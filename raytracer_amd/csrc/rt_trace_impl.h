@@ -1021,13 +1021,17 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
                 V3 nd;
                 bool attenuate = true;
                 V3 att = v3(mA.x, mA.y, mA.z);
+                // Lambertian and metal both draw one random direction and nothing else: the rejection loop runs once
+                // for the lanes of both materials together instead of once per branch (same draws, same order).
+                V3 rd = v3(0.0f, 0.0f, 0.0f);
+                if (mtype != 2) rd = random_direction<MODE>(L.rng);
                 if (mtype == 0) {                                           // Lambertian, Main.c:562-573
-                    nd = add(n, random_direction<MODE>(L.rng));
+                    nd = add(n, rd);
                     const float s = 1e-8f;
                     if (fabsf(nd.x) < s && fabsf(nd.y) < s && fabsf(nd.z) < s) nd = n;
                 } else if (mtype == 1) {                                    // Metal, Main.c:575-581
                     V3 refl = reflect(L.d, n);
-                    nd = add(unit(refl), scale(random_direction<MODE>(L.rng), mA.w));
+                    nd = add(unit(refl), scale(rd, mA.w));
                     attenuate = dot(nd, n) > 0.0f;
                 } else {                                                    // Dielectric, Main.c:583-611
                     att = v3(1.0f, 1.0f, 1.0f);
