@@ -94,19 +94,26 @@ __device__ __forceinline__ float rng_float(Rng &r)
 template <int MODE>
 __device__ __forceinline__ float rng_pm1(Rng &r) { return -1.0f + 2.0f * rng_float<MODE>(r); }
 
-// vec3f_random_direction, util.c:170-184
+// vec3f_random_direction, util.c:170-184.  The loop only looks for the sample; the normalisation (an IEEE square
+// root and divide in the strict build) runs once after it, for all lanes together, instead of in whichever
+// iteration a lane happens to leave the loop.
 template <int MODE>
 __device__ __forceinline__ V3 random_direction(Rng &r)
 {
-    for (int i = 0; i < 100; i++) {
-        V3 p;
-        p.x = rng_pm1<MODE>(r);
-        p.y = rng_pm1<MODE>(r);
-        p.z = rng_pm1<MODE>(r);
-        float l2 = lensq(p);
-        if (1e-15 < (double)l2 && l2 <= 1.0f) return scale(p, rt_inv_sqrt(l2));
+    V3 p = v3(0.0f, 0.0f, 0.0f);
+    float l2 = 0.0f;
+    bool found = false;
+    for (int i = 0; i < 100 && !found; i++) {
+        V3 c;
+        c.x = rng_pm1<MODE>(r);
+        c.y = rng_pm1<MODE>(r);
+        c.z = rng_pm1<MODE>(r);
+        const float cl = lensq(c);
+        if (1e-15 < (double)cl && cl <= 1.0f) { found = true; p = c; l2 = cl; }
     }
-    return v3(0.0f, 0.0f, 0.0f);
+    asm volatile("" : "+v"(l2));            // keeps the normalisation behind the loop
+    if (!found) return v3(0.0f, 0.0f, 0.0f);
+    return scale(p, rt_inv_sqrt(l2));
 }
 
 // vec3f_random_direction_2d, util.c:186-200
