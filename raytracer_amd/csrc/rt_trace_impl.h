@@ -94,6 +94,12 @@ __device__ __forceinline__ float rng_float(Rng &r)
 template <int MODE>
 __device__ __forceinline__ float rng_pm1(Rng &r) { return -1.0f + 2.0f * rng_float<MODE>(r); }
 
+// The reference accepts a rejection sample when 1e-15 < (double)l2 && l2 <= 1 (util.c:176, 192).  The nearest f32
+// to 1e-15 lies above it and the f32 below that lies below it, so for an f32 l2 the first test is l2 >= 1e-15f:
+// the same decision without the conversion and the f64 compare.
+static_assert(1e-15f == 0x1.203afap-50f && (double)0x1.203afap-50f > 1e-15 && (double)0x1.203af8p-50f < 1e-15, "f32 form of the 1e-15 threshold");
+__device__ __forceinline__ bool accepts(float l2) { return l2 >= 1e-15f && l2 <= 1.0f; }
+
 // vec3f_random_direction, util.c:170-184.  The loop only looks for the sample; the normalisation (an IEEE square
 // root and divide in the strict build) runs once after it, for all lanes together, instead of in whichever
 // iteration a lane happens to leave the loop.
@@ -109,7 +115,7 @@ __device__ __forceinline__ V3 random_direction(Rng &r)
         c.y = rng_pm1<MODE>(r);
         c.z = rng_pm1<MODE>(r);
         const float cl = lensq(c);
-        if (1e-15 < (double)cl && cl <= 1.0f) { found = true; p = c; l2 = cl; }
+        if (accepts(cl)) { found = true; p = c; l2 = cl; }
     }
     asm volatile("" : "+v"(l2));            // keeps the normalisation behind the loop
     if (!found) return v3(0.0f, 0.0f, 0.0f);
@@ -126,7 +132,7 @@ __device__ __forceinline__ V3 random_direction_2d(Rng &r)
         p.y = rng_pm1<MODE>(r);
         p.z = 0.0f;
         float l2 = lensq(p);
-        if (1e-15 < (double)l2 && l2 <= 1.0f) return p;
+        if (accepts(l2)) return p;
     }
     return v3(0.0f, 0.0f, 0.0f);
 }
@@ -1015,35 +1021,44 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
             bool done = false;
             V3 add_col = v3(0.0f, 0.0f, 0.0f);
 #if RT_STRICT
+            // The three materials and the sky each normalise one vector with an IEEE square root and divide (the
+            // reflected direction for metal, the incoming direction for glass and for the sky): the lanes of all four
+            // cases do it together, once, instead of in four places one after another; likewise the one random
+            // direction that Lambertian and metal draw (same draws, same order, same values).
+            int mtype = -1;
+            float4 mA = make_float4(0.0f, 0.0f, 0.0f, 0.0f), mB = mA;
+            V3 P = L.o, n = v3(0.0f, 0.0f, 0.0f);
+            bool front = false;
             if (hit >= 0) {
                 const float4 g = s_geom[hit];
-                const float4 mA = s_matA[hit];
-                const float4 mB = s_matB[hit];
+                mA = s_matA[hit];
+                mB = s_matB[hit];
                 const V3 ctr = v3(g.x, g.y, g.z);
-                const V3 P = add(L.o, scale(L.d, closest));                 // RAY_AT
+                P = add(L.o, scale(L.d, closest));                          // RAY_AT
                 const V3 outward = scale(sub(P, ctr), mB.z);                // * (1.0f / radius)
-                const bool front = dot(L.d, outward) < 0.0f;                // set_face_normal
-                const V3 n = front ? outward : scale(outward, -1.0f);
-                const int mtype = __float_as_int(mB.y);
+                front = dot(L.d, outward) < 0.0f;                           // set_face_normal
+                n = front ? outward : scale(outward, -1.0f);
+                mtype = __float_as_int(mB.y);
+            }
+            V3 rd = v3(0.0f, 0.0f, 0.0f);
+            if (mtype == 0 || mtype == 1) rd = random_direction<MODE>(L.rng);
+            V3 normed = v3(0.0f, 0.0f, 0.0f);
+            if (mtype != 0) normed = unit(mtype == 1 ? reflect(L.d, n) : L.d);
+            if (hit >= 0) {
                 V3 nd;
                 bool attenuate = true;
                 V3 att = v3(mA.x, mA.y, mA.z);
-                // Lambertian and metal both draw one random direction and nothing else: the rejection loop runs once
-                // for the lanes of both materials together instead of once per branch (same draws, same order).
-                V3 rd = v3(0.0f, 0.0f, 0.0f);
-                if (mtype != 2) rd = random_direction<MODE>(L.rng);
                 if (mtype == 0) {                                           // Lambertian, Main.c:562-573
                     nd = add(n, rd);
                     const float s = 1e-8f;
                     if (fabsf(nd.x) < s && fabsf(nd.y) < s && fabsf(nd.z) < s) nd = n;
                 } else if (mtype == 1) {                                    // Metal, Main.c:575-581
-                    V3 refl = reflect(L.d, n);
-                    nd = add(unit(refl), scale(rd, mA.w));
+                    nd = add(normed, scale(rd, mA.w));
                     attenuate = dot(nd, n) > 0.0f;
                 } else {                                                    // Dielectric, Main.c:583-611
                     att = v3(1.0f, 1.0f, 1.0f);
                     const float ri = front ? rt_div(1.0f, mB.x) : mB.x;
-                    const V3 ud = unit(L.d);
+                    const V3 ud = normed;
                     const float cos_theta = fminf(dot(scale(ud, -1.0f), n), 1.0f);
                     const float sin_theta = rt_sqrt(1.0f - cos_theta * cos_theta);
                     bool refl = ri * sin_theta > 1.0f;
@@ -1098,7 +1113,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
 #endif
             } else {                                                        // sky, Main.c:744-758
 #if RT_STRICT
-                const V3 ud = unit(L.d);
+                const V3 ud = normed;
 #else
                 const V3 ud = L.d;                                          // already unit length (or zero)
 #endif
