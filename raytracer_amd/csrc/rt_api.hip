@@ -837,7 +837,7 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
             int32_t mt = s.mat_type;
             float mtf;
             memcpy(&mtf, &mt, 4);
-            matB[i] = make_float4(s.refraction_index, mtf, 1.0f / s.radius, s.radius);        // Main.c:679
+            matB[i] = make_float4(s.refraction_index, mtf, 1.0f / s.radius, 1.0f / s.refraction_index);   // Main.c:679, :589
         } else {
             geom[i] = make_float4(0.0f, 0.0f, 0.0f, -std::numeric_limits<float>::infinity());
         }

@@ -14,7 +14,7 @@ namespace rtmi {
 // space-filling curve; orig[] maps back to the caller's indices).  One float4 per sphere and array:
 //   geom[i] = { cx, cy, cz, r*r }            -- all hit_sphere (Main.c:625-653) needs to reject
 //   matA[i] = { albedo.r, albedo.g, albedo.b, fuzz }
-//   matB[i] = { refraction_index, bits(mat_type), 1.0f/r, r }
+//   matB[i] = { refraction_index, bits(mat_type), 1.0f/r, 1.0f/refraction_index }
 // geom is padded to a multiple of kGeomPad with never-hit entries (r*r = -inf).
 constexpr int kGeomPad = 8;
 // Both builds: the scan over the sphere list is a conservative filter, two spheres per packed-FP32

@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
                     attenuate = dot(nd, n) > 0.0f;
                 } else {                                                    // Dielectric, Main.c:583-611
                     att = v3(1.0f, 1.0f, 1.0f);
-                    const float ri = front ? rt_div(1.0f, mB.x) : mB.x;
+                    const float ri = front ? mB.w : mB.x;                  // 1.0f / ior, divided on the host (the same IEEE quotient)
                     const V3 ud = normed;
                     const float cos_theta = fminf(dot(scale(ud, -1.0f), n), 1.0f);
                     const float sin_theta = rt_sqrt(1.0f - cos_theta * cos_theta);
@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
                 // Metal
                 const V3 nd_m = add(refl, scale(rnd, mA.w));                // |refl| = 1: d and n are unit vectors
                 // Dielectric
-                const float ri = front ? __builtin_amdgcn_rcpf(mB.x) : mB.x;
+                const float ri = front ? mB.w : mB.x;                       // 1 / ior from the host
                 const float cos_theta = fminf(cosi, 1.0f);
                 const float sin_theta = rt_sqrt(fmaxf(0.0f, fmaf(-cos_theta, cos_theta, 1.0f)));
                 const bool reflects = (ri * sin_theta > 1.0f) || (reflectance(cos_theta, ri) > u);
