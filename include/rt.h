@@ -70,16 +70,30 @@ typedef struct rt_camera_params {
  *     key    = mix32( mix32(pixel + mix32(seed ^ 0x6A09E667)) ^ (sample * 0x9E3779B9) )
  *     draw_n = mix32(key + n * 0x9E3779B9),  n = 0,1,2,... within one sample
  *     u      = (draw_n >> 8) * 2^-24                       (replaces RAND_FLOAT, include/util.h:93)
- * pixel = x + y*width in the FULL image, sample = sample_base + index within the call.  In the
- * strict build draws are consumed in the reference's order (jitter x, jitter y, defocus disk,
- * then per bounce the scatter draws); the fast build uses the same generator with its own
- * samplers. */
+ * pixel = x + y*width in the FULL image, sample = sample_base + index within the call.  What the
+ * draws of a sample are used for depends on the build (RT_BUILD_*, below). */
 enum {
     RT_MODE_MC      = 0,  /* Monte-Carlo: counter-based RNG keyed (seed, pixel, sample) */
     RT_MODE_CONST_U = 1   /* deterministic: every random draw returns 0.5, i.e. the
                              reference with fast_rand() == 16384: centre sample, ray
                              origin = camera.pos, scatter along the normal */
 };
+
+/* Three builds of the path-tracing kernel.
+ *   RT_BUILD_EXACT  (default) every f32 operation of get_ray, hit_sphere, hit, ray_scatter, ray_color and the
+ *                   pixel finish is evaluated in the reference's order with IEEE-rounded sqrt and divide and no
+ *                   FMA contraction.  The reference's two rejection samplers (vec3f_random_direction(_2d),
+ *                   src/util.c:170-200) are replaced by loop-free maps with the same distributions, defined so
+ *                   that a CPU reproduces them bit for bit: per sample one draw for the pixel jitter (16 bits per
+ *                   axis, stratum centres), one for the defocus disk (radius sqrt((k + 0.5) / 65536), azimuth
+ *                   2 pi i / 65536), then per bounce one draw for a Lambertian / metal direction
+ *                   (z = (65535 - 2 k) / 65536, azimuth as before) or one uniform for the glass decision.
+ *                   RT_MODE_CONST_U output equals the reference's, bit for bit.
+ *   RT_BUILD_STRICT the same arithmetic with the reference's rejection samplers and the reference's order of
+ *                   draws (jitter x, jitter y, defocus disk, then per bounce the scatter draws).
+ *   RT_BUILD_FAST   FMA contraction, unit-length directions, hardware rsqrt / rcp / sin / cos: the same estimator,
+ *                   statistically equivalent images, not reproducible on a CPU. */
+enum { RT_BUILD_EXACT = 0, RT_BUILD_STRICT = 1, RT_BUILD_FAST = 2 };
 
 typedef struct rt_stats {
     uint64_t samples;        /* pixel samples traced by this call                  */
@@ -96,9 +110,7 @@ enum { RT_CHUNK_AUTO = -1 };  /* rt_opts.chunk_spp: let the library choose the u
 
 typedef struct rt_opts {
     int32_t  mode;           /* RT_MODE_*                                            */
-    int32_t  strict_fp;      /* 1: no FMA contraction, IEEE sqrt/div: results are bit-
-                                identical to the CPU mirror; 0: fast kernel (FMA,
-                                normalised directions), statistically equivalent     */
+    int32_t  build;          /* RT_BUILD_*: which build of the kernel runs (0 = exact)  */
     uint32_t seed;           /* RNG seed (MC mode)                                   */
     uint32_t sample_base;    /* index of the first sample (progressive frames pass
                                 frame*spp so that frames draw disjoint streams)      */
@@ -164,7 +176,7 @@ int rt_set_world(const rt_sphere *spheres, size_t count);
  * `rgba` is caller-owned HOST memory, width*height*4 bytes, row 0 = top, alpha 255
  * (color4_t, include/util.h:227-233; BUF_AT, include/base_graphics.h:13).  With
  * opts->part_count > 1 only the owned rows are written, at their place in the
- * full image.  `opts` may be NULL (MC, fast kernel, seed 0, all rows, RT_CHUNK_AUTO). */
+ * full image.  `opts` may be NULL (MC, exact build, seed 0, all rows, RT_CHUNK_AUTO). */
 int rt_render(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height,
               int spp, int max_depth, const rt_opts *opts);
 
@@ -176,7 +188,8 @@ int rt_render_device(const rt_camera *cam, uint8_t *rgba_dev, uint32_t width, ui
                      int spp, int max_depth, const rt_opts *opts);
 
 /* No counterpart in the reference.  For callers that cannot allocate device memory around the
- * call (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the same
+ * call (tight serving loops, harnesses that forbid hipMalloc, hosts whose memory pool is handed out
+ * once): the same
  * as rt_render_device, but the per-chunk partial sums and the work/ray counters live in a fixed
  * array of RT_NOALLOC_SCRATCH_BYTES in the library's code object (one copy per GPU, held until the
  * process ends) instead of buffers the library grows on demand; the call runs no hipMalloc, hipFree
@@ -185,7 +198,9 @@ int rt_render_device(const rt_camera *cam, uint8_t *rgba_dev, uint32_t width, ui
  * RT_NOALLOC_SCRATCH_BYTES - 256 (1920x1080 in up to two chunks; chunk_spp = 0 is always one
  * chunk), else RT_ERR_ARG with the sizes in rt_last_error(); opts->rows is not supported
  * (part_index / part_count are).  Results equal rt_render_device's for the same arguments, bit for
- * bit.  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU race;
+ * bit.  The call is synchronous: it launches on the library's own stream and waits for it, so it
+ * cannot be recorded into a caller's HIP graph; what it guarantees is the absence of allocation.
+ * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU race;
  * the library's other entry points do not touch the array. */
 #define RT_NOALLOC_SCRATCH_BYTES (64u << 20)
 int rt_render_device_noalloc(const rt_camera *cam, uint8_t *rgba_dev, uint32_t width, uint32_t height,
@@ -196,7 +211,7 @@ int rt_render_device_noalloc(const rt_camera *cam, uint8_t *rgba_dev, uint32_t w
  * sample_base + frame_index*spp ...) to a per-pixel sum kept on the device and writes the
  * image of ALL samples so far.  frame_index 0 starts a sequence; frames must follow in order
  * with the same size, spp and partition.  After F frames the result equals, bit for bit in the
- * strict build, one rt_render call with F*spp samples and the same chunk_spp (which must
+ * exact and strict builds, one rt_render call with F*spp samples and the same chunk_spp (which must
  * divide spp).  opts->accum_out receives the running mean. */
 int rt_render_progressive(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t height,
                           int spp, int max_depth, const rt_opts *opts, uint32_t frame_index);

@@ -9,7 +9,7 @@
  * (:1056-1068).  The driver then writes the framebuffer the reference would hand to
  * present_frame (Main.c:1445).
  *
- * usage: ref_dropin_<s3|sf> <width> <spp> <depth> <out.rgba> [strict] [seed] [chunk]
+ * usage: ref_dropin_<s3|sf> <width> <spp> <depth> <out.rgba> [build] [seed] [chunk]
  */
 int ref_lcg_fast_rand(void);      /* the reference's fast_rand, renamed at build time */
 int fast_rand(void) { return ref_lcg_fast_rand(); }
@@ -17,11 +17,11 @@ int fast_rand(void) { return ref_lcg_fast_rand(); }
 int main(int argc, char **argv)
 {
     if (argc < 5) {
-        fprintf(stderr, "usage: %s <width> <spp> <depth> <out.rgba> [strict] [seed] [chunk]\n", argv[0]);
+        fprintf(stderr, "usage: %s <width> <spp> <depth> <out.rgba> [build] [seed] [chunk]\n", argv[0]);
         return 2;
     }
     static rt_opts opts;
-    opts.strict_fp = argc > 5 ? atoi(argv[5]) : 0;
+    opts.build = argc > 5 ? atoi(argv[5]) : 0;
     opts.seed = argc > 6 ? (uint32_t)strtoul(argv[6], NULL, 0) : 0;
     opts.chunk_spp = argc > 7 ? atoi(argv[7]) : RT_CHUNK_AUTO;
     g_dropin_opts = &opts;

@@ -99,6 +99,7 @@ uint32_t refcpu_counter_draw(uint32_t key, uint32_t n)
 static inline float rng_float(rng_t *r)
 {
     switch (r->mode) {
+    case REFCPU_RNG_COUNTER_DIRECT:
     case REFCPU_RNG_COUNTER: {
         uint32_t x = refcpu_counter_draw(r->key, r->n++);
         return (float)(x >> 8) * (1.0f / 16777216.0f);
@@ -144,6 +145,58 @@ static v3 random_direction_2d(rng_t *r)
     }
     v3 z = { 0.0f, 0.0f, 0.0f };
     return z;
+}
+
+/* ---- loop-free samplers of the GPU path's exact build (REFCPU_RNG_COUNTER_DIRECT) ------------
+ * They replace the two rejection samplers above (util.c:170-200) with maps of the same
+ * distributions.  Definition (include/rt.h, RT_BUILD_EXACT): one 32-bit draw gives two 16-bit
+ * fields; every conversion and scaling below is exact in f32, sqrtf is IEEE, and each polynomial
+ * step is a single rounded operation or an fmaf, so that any IEEE machine gets the same bits. */
+
+/* cos and sin of 2 pi i / 65536: the nearest quarter turn is taken off in integers, the rest lies
+ * within +-pi/4 (Cephes single-precision kernels), quarter turns go back by swap and sign. */
+static inline void sincos_turns16(uint32_t i, float *c, float *s)
+{
+    uint32_t q = (i + 8192u) >> 14;
+    float th = (float)((int)i - (int)(q << 14)) * 9.58737992428525768e-5f;
+    float z = th * th;
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    float s0 = fmaf(ps * z, th, th);
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    float c0 = fmaf(pc, z * z, fmaf(-0.5f, z, 1.0f));
+    float c1 = (q & 1u) ? s0 : c0, s1 = (q & 1u) ? c0 : s0;
+    *c = ((q + 1u) & 2u) ? -c1 : c1;
+    *s = (q & 2u) ? -s1 : s1;
+}
+
+static inline uint32_t rng_bits(rng_t *r) { return refcpu_counter_draw(r->key, r->n++); }
+
+static v3 sphere_direction_direct(rng_t *r)
+{
+    uint32_t x = rng_bits(r);
+    float z = fmaf((float)(x >> 16), -1.0f / 32768.0f, 65535.0f / 65536.0f);
+    float rad = sqrtf(fmaf(-z, z, 1.0f));
+    float c, s;
+    sincos_turns16(x & 0xffffu, &c, &s);
+    v3 d = { rad * c, rad * s, z };
+    return d;
+}
+
+static v3 disk_point_direct(rng_t *r)
+{
+    uint32_t x = rng_bits(r);
+    float rad = sqrtf(fmaf((float)(x >> 16), 1.0f / 65536.0f, 1.0f / 131072.0f));
+    float c, s;
+    sincos_turns16(x & 0xffffu, &c, &s);
+    v3 p = { rad * c, rad * s, 0.0f };
+    return p;
+}
+
+static inline v3 scatter_direction(rng_t *r)
+{
+    return r->mode == REFCPU_RNG_COUNTER_DIRECT ? sphere_direction_direct(r) : random_direction(r);
 }
 
 /* ---- scene / hit ---------------------------------------------------------- */
@@ -223,7 +276,7 @@ static inline int scatter(const ray_t *in, const hit_t *rec, v3 *atten, ray_t *o
     const rt_sphere *s = rec->s;
     switch (s->mat_type) {
     case RT_MAT_LAMBERTIAN: {
-        v3 d = v3_add(rec->norm, random_direction(r));
+        v3 d = v3_add(rec->norm, scatter_direction(r));
         if (v3_near_zero(d)) d = rec->norm;
         out->orig = rec->p; out->dir = d;
         *atten = V(s->albedo);
@@ -231,7 +284,7 @@ static inline int scatter(const ray_t *in, const hit_t *rec, v3 *atten, ray_t *o
     }
     case RT_MAT_METAL: {
         v3 refl = v3_reflect(in->dir, rec->norm);
-        refl = v3_add(v3_unit(refl), v3_scale(random_direction(r), s->fuzz));
+        refl = v3_add(v3_unit(refl), v3_scale(scatter_direction(r), s->fuzz));
         out->orig = rec->p; out->dir = refl;
         *atten = V(s->albedo);
         return v3_dot(out->dir, rec->norm) > 0;
@@ -290,8 +343,17 @@ static v3 ray_color(const job_t *j, ray_t ray, int depth, rng_t *r, uint64_t *ra
 static inline ray_t get_ray(const job_t *j, int x, int y, rng_t *r)
 {
     const rt_camera *c = j->cam;
-    float ox = rng_float(r) - 0.5f;
-    float oy = rng_float(r) - 0.5f;
+    const int direct = r->mode == REFCPU_RNG_COUNTER_DIRECT;
+    float ox, oy;
+    if (direct) {                                   /* one draw, stratum centres (k + 0.5) / 65536 - 0.5 */
+        uint32_t b = rng_bits(r);
+        const float bias = -0.5f + 1.0f / 131072.0f;
+        ox = fmaf((float)(b >> 16), 1.0f / 65536.0f, bias);
+        oy = fmaf((float)(b & 0xffffu), 1.0f / 65536.0f, bias);
+    } else {
+        ox = rng_float(r) - 0.5f;
+        oy = rng_float(r) - 0.5f;
+    }
     v3 ps;
     ps.x = c->pixel00_loc.x + ((x + ox) * c->pixel_delta_u.x) + ((y + oy) * c->pixel_delta_v.x);
     ps.y = c->pixel00_loc.y + ((x + ox) * c->pixel_delta_u.y) + ((y + oy) * c->pixel_delta_v.y);
@@ -300,7 +362,7 @@ static inline ray_t get_ray(const job_t *j, int x, int y, rng_t *r)
     if (c->defocus_angle <= 0) {
         org = V(c->pos);
     } else {
-        v3 p = random_direction_2d(r);
+        v3 p = direct ? disk_point_direct(r) : random_direction_2d(r);
         org = v3_add(V(c->pos), v3_add(v3_scale(V(c->defocus_disk_u), p.x), v3_scale(V(c->defocus_disk_v), p.y)));
     }
     ray_t ray = { org, v3_sub(ps, org) };
@@ -361,7 +423,7 @@ static void pixel_counter(const job_t *j, uint32_t x, uint32_t y, uint64_t *rays
         v3 part = { 0, 0, 0 };
         for (int s = s0; s < s1; s++) {
             rng_t r;
-            r.mode = REFCPU_RNG_COUNTER;
+            r.mode = j->o->rng;
             r.lcg = 0;
             r.key = refcpu_counter_key(j->o->seed, pix, j->o->sample_base + (uint32_t)s);
             r.n = 0;
@@ -394,7 +456,7 @@ static void render_tile(const job_t *j, const tile_t *t, uint64_t *rays)
     if (mode == REFCPU_RNG_LCG_TILES) r.lcg = t->x0 * 1000u + t->y0 + 1u;        /* Main.c:963 */
     for (uint32_t y = t->y0; y < t->y1; ++y)
         for (uint32_t x = t->x0; x < t->x1; ++x) {
-            if (mode == REFCPU_RNG_COUNTER) pixel_counter(j, x, y, rays);
+            if (mode == REFCPU_RNG_COUNTER || mode == REFCPU_RNG_COUNTER_DIRECT) pixel_counter(j, x, y, rays);
             else pixel_stream(j, x, y, &r, rays);
         }
 }

@@ -25,12 +25,16 @@ enum {
     REFCPU_RNG_LCG_SERIAL = 1, /* same LCG, one stream from seed 0 over the whole image
                                   in render_all's order (Main.c:1099-1113)            */
     REFCPU_RNG_COUNTER    = 2, /* counter-based generator of the GPU path             */
-    REFCPU_RNG_CONST_U    = 3  /* every draw is 16384/32768 = 0.5                      */
+    REFCPU_RNG_CONST_U    = 3, /* every draw is 16384/32768 = 0.5                      */
+    REFCPU_RNG_COUNTER_DIRECT = 4 /* counter generator with the loop-free samplers of the
+                                  GPU path's exact build (RT_BUILD_EXACT, include/rt.h) in
+                                  place of the reference's rejection loops (util.c:170-200);
+                                  everything else as REFCPU_RNG_COUNTER                 */
 };
 
 typedef struct refcpu_opts {
     int32_t  rng;            /* REFCPU_RNG_*                                          */
-    uint32_t seed;           /* COUNTER mode                                          */
+    uint32_t seed;           /* COUNTER modes                                         */
     uint32_t sample_base;    /* COUNTER mode                                          */
     int32_t  chunk_spp;      /* COUNTER mode: 0 = spp                                 */
     int32_t  threads;        /* 0 = 2 * online cores (Main.c:1002)                    */

@@ -12,7 +12,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "librefcpu.so")
 
-RNG_LCG_TILES, RNG_LCG_SERIAL, RNG_COUNTER, RNG_CONST_U = 0, 1, 2, 3
+RNG_LCG_TILES, RNG_LCG_SERIAL, RNG_COUNTER, RNG_CONST_U, RNG_COUNTER_DIRECT = 0, 1, 2, 3, 4
 
 
 class Vec3(C.Structure):

@@ -15,6 +15,8 @@ LIB_PATH = os.environ.get("RTMI_LIB", os.path.join(HERE, "librtmi.so"))   # RTMI
 CSRC = os.path.join(HERE, "csrc")
 
 MODE_MC, MODE_CONST_U = 0, 1
+BUILD_EXACT, BUILD_STRICT, BUILD_FAST = 0, 1, 2          # RT_BUILD_*
+BUILDS = {"exact": BUILD_EXACT, "strict": BUILD_STRICT, "fast": BUILD_FAST}
 CHUNK_AUTO = -1
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
 
@@ -47,7 +49,7 @@ class Stats(C.Structure):
 
 
 class Opts(C.Structure):
-    _fields_ = [("mode", C.c_int32), ("strict_fp", C.c_int32), ("seed", C.c_uint32),
+    _fields_ = [("mode", C.c_int32), ("build", C.c_int32), ("seed", C.c_uint32),
                 ("sample_base", C.c_uint32), ("chunk_spp", C.c_int32), ("tile_rows", C.c_int32),
                 ("part_index", C.c_int32), ("part_count", C.c_int32),
                 ("hit_index_out", C.c_void_p), ("accum_out", C.c_void_p), ("stats", C.c_void_p),
@@ -203,27 +205,35 @@ def part_row_map(height, tile_rows, part_index, part_count):
                     dtype=np.int64)
 
 
-def _opts(mode, strict_fp, seed, sample_base, chunk_spp, tile_rows, part_index, part_count, rows=None):
+def build_id(build=None, strict_fp=False):
+    """RT_BUILD_* from a name ("exact", "strict", "fast"), a number, or -- when `build` is None -- from
+    strict_fp: True = the strict build (reference samplers), False = the exact build (the default)."""
+    if build is None:
+        return BUILD_STRICT if strict_fp else BUILD_EXACT
+    return BUILDS[build] if isinstance(build, str) else int(build)
+
+
+def _opts(mode, strict_fp, seed, sample_base, chunk_spp, tile_rows, part_index, part_count, rows=None, build=None):
     o = Opts()
     if rows is not None:
         rows = np.ascontiguousarray(rows, dtype=np.uint32)
         o._rows_keepalive = rows
         o.rows, o.row_count = rows.ctypes.data, len(rows)
-    o.mode, o.strict_fp, o.seed, o.sample_base = mode, int(bool(strict_fp)), seed, sample_base
+    o.mode, o.build, o.seed, o.sample_base = mode, build_id(build, strict_fp), seed, sample_base
     o.chunk_spp, o.tile_rows, o.part_index, o.part_count = chunk_spp, tile_rows, part_index, part_count
     return o
 
 
 def render(cam, width, height, spp, max_depth, mode=MODE_MC, strict_fp=False, seed=0, sample_base=0,
            chunk_spp=0, tile_rows=0, part_index=0, part_count=0, want_hit=False, want_accum=False,
-           out=None, rows=None):
+           out=None, rows=None, build=None):
     """rt_render into host memory.  Returns dict(rgba, hit, accum, stats)."""
     rgba = out if out is not None else np.zeros((height, width, 4), dtype=np.uint8)
     assert rgba.dtype == np.uint8 and rgba.shape == (height, width, 4) and rgba.flags.c_contiguous
     hit = np.full((height, width), -2, dtype=np.int32) if want_hit else None
     acc = np.zeros((height, width, 3), dtype=np.float32) if want_accum else None
     st = Stats()
-    o = _opts(mode, strict_fp, seed, sample_base, chunk_spp, tile_rows, part_index, part_count, rows)
+    o = _opts(mode, strict_fp, seed, sample_base, chunk_spp, tile_rows, part_index, part_count, rows, build)
     o.hit_index_out = hit.ctypes.data if want_hit else None
     o.accum_out = acc.ctypes.data if want_accum else None
     o.stats = C.addressof(st)
@@ -233,12 +243,12 @@ def render(cam, width, height, spp, max_depth, mode=MODE_MC, strict_fp=False, se
 
 
 def render_progressive(cam, width, height, spp, max_depth, frame_index, mode=MODE_MC, strict_fp=False,
-                       seed=0, sample_base=0, chunk_spp=0, want_accum=False, out=None):
+                       seed=0, sample_base=0, chunk_spp=0, want_accum=False, out=None, build=None):
     """rt_render_progressive: adds one frame of `spp` samples; returns the image of all frames so far."""
     rgba = out if out is not None else np.zeros((height, width, 4), dtype=np.uint8)
     acc = np.zeros((height, width, 3), dtype=np.float32) if want_accum else None
     st = Stats()
-    o = _opts(mode, strict_fp, seed, sample_base, chunk_spp, 0, 0, 0)
+    o = _opts(mode, strict_fp, seed, sample_base, chunk_spp, 0, 0, 0, None, build)
     o.accum_out = acc.ctypes.data if want_accum else None
     o.stats = C.addressof(st)
     _check(lib().rt_render_progressive(C.byref(cam), rgba.ctypes.data, width, height, spp, max_depth,
@@ -256,11 +266,11 @@ def chunk_for(width, height, spp, chunk_spp=CHUNK_AUTO, progressive=False):
 
 def render_device(cam, rgba_dev_ptr, width, height, spp, max_depth, mode=MODE_MC, strict_fp=False,
                   seed=0, sample_base=0, chunk_spp=0, tile_rows=0, part_index=0, part_count=0,
-                  hit_dev_ptr=None, accum_dev_ptr=None, rows=None, no_alloc=False):
+                  hit_dev_ptr=None, accum_dev_ptr=None, rows=None, no_alloc=False, build=None):
     """rt_render_device: outputs are raw device pointers (e.g. torch.Tensor.data_ptr()).
     no_alloc=True calls rt_render_device_noalloc (scratch in the library's static device array)."""
     st = Stats()
-    o = _opts(mode, strict_fp, seed, sample_base, chunk_spp, tile_rows, part_index, part_count, rows)
+    o = _opts(mode, strict_fp, seed, sample_base, chunk_spp, tile_rows, part_index, part_count, rows, build)
     o.hit_index_out = hit_dev_ptr
     o.accum_out = accum_dev_ptr
     o.stats = C.addressof(st)

@@ -233,6 +233,45 @@ int scan_variant(const Ctx &g)
     return g.n > kMaxSpheresLds ? kScanVectorGlobal : kScanVectorLds;
 }
 
+trace_fn kernel_of(int build, int mode, int variant)
+{
+    return build == kBuildFast ? trace_kernel_fast(mode, variant)
+         : build == kBuildStrict ? trace_kernel_strict(mode, variant) : trace_kernel_exact(mode, variant);
+}
+
+// Sets the dynamic-LDS attribute of the kernel instantiation (build, mode, variant) if it differs from
+// the cached one; the first call per instantiation also makes the runtime load its code object.
+hipError_t prepare_trace(LaunchCache &c, int build, int mode, int variant, size_t lds_bytes)
+{
+    mode = mode == 1 ? 1 : 0;
+    if (c.attr_lds[build][mode][variant] == lds_bytes) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute((const void *)kernel_of(build, mode, variant),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess) c.attr_lds[build][mode][variant] = lds_bytes;
+    return e;
+}
+
+hipError_t launch_trace(LaunchCache &c, int build, const TraceParams &p, int variant, int blocks, size_t lds_bytes, hipStream_t s)
+{
+    const int mode = p.mode == 1 ? 1 : 0;
+    hipError_t e = prepare_trace(c, build, mode, variant, lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel_of(build, mode, variant), dim3(blocks), dim3(block_threads_of(variant)), lds_bytes, s, p);
+    return hipGetLastError();
+}
+
+int trace_blocks_per_cu(LaunchCache &c, int build, int variant, size_t lds_bytes)
+{
+    if (c.occ_lds[build][variant] == lds_bytes) return c.occ_blocks[build][variant];
+    int n = 0;
+    if (prepare_trace(c, build, 0, variant, lds_bytes) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel_of(build, 0, variant), block_threads_of(variant), lds_bytes) != hipSuccess)
+        return 1;
+    c.occ_lds[build][variant] = lds_bytes;
+    c.occ_blocks[build][variant] = n > 0 ? n : 1;
+    return c.occ_blocks[build][variant];
+}
+
 // f16 pieces of the matrix scan's sphere image: x = p[0] + p[1] + e, |e| <= 2^-24 |x| (round to nearest even)
 uint16_t f16_bits(float x)
 {
@@ -274,6 +313,8 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
     if (spp < 1) return fail(RT_ERR_ARG, "rt_render: spp must be >= 1 (got %d)", spp);
     if (max_depth < 0) return fail(RT_ERR_ARG, "rt_render: max_depth must be >= 0 (got %d)", max_depth);
     if (o.mode != RT_MODE_MC && o.mode != RT_MODE_CONST_U) return fail(RT_ERR_ARG, "rt_render: unknown mode %d", o.mode);
+    if (o.build < 0 || o.build >= kBuilds) return fail(RT_ERR_ARG, "rt_render: unknown build %d", o.build);
+    const int build = o.build;
     if (o.tile_rows < 0) return fail(RT_ERR_ARG, "rt_render: negative tile_rows");
     const int chunk = call.chunk;
     if (chunk < 1 || chunk > spp) return fail(RT_ERR_ARG, "rt_render: bad chunk_spp %d for %d spp", chunk, spp);
@@ -401,8 +442,8 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             tp.total_units = units;
 
             const int variant = scan_variant(g);
-            const size_t lds = trace_lds_bytes(variant, o.strict_fp != 0, g.n_pad, g.ntiles);
-            const int per_cu = o.strict_fp ? trace_blocks_per_cu_strict(g.launch, variant, lds) : trace_blocks_per_cu_fast(g.launch, variant, lds);
+            const size_t lds = trace_lds_bytes(variant, reference_arithmetic(build), g.n_pad, g.ntiles);
+            const int per_cu = trace_blocks_per_cu(g.launch, build, variant, lds);
             uint64_t blocks = (uint64_t)g.num_cu * (uint64_t)per_cu;
             const uint64_t need = (units + block_threads_of(variant) - 1) / block_threads_of(variant);
             if (blocks > need) blocks = need;
@@ -424,8 +465,7 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             }
 
             HIP_TRY(hipEventRecord(g.ev0, g.stream));
-            HIP_TRY(o.strict_fp ? launch_trace_strict(g.launch, tp, variant, (int)blocks, lds, g.stream)
-                                : launch_trace_fast(g.launch, tp, variant, (int)blocks, lds, g.stream));
+            HIP_TRY(launch_trace(g.launch, build, tp, variant, (int)blocks, lds, g.stream));
             HIP_TRY(hipEventRecord(g.ev1, g.stream));
             ResolveParams rp;
             rp.partial = d_partial; rp.nchunks = nchunks; rp.npix = npix;
@@ -944,14 +984,13 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
         g.nbig = nbig;
         memcpy(g.big, big, sizeof big);
         g.c_near = (float)c_near;
-        // Look up the launch geometry of both builds now (code objects load, LDS attributes are set,
+        // Look up the launch geometry of every build now (code objects load, LDS attributes are set,
         // occupancy is queried), so that no render call after this one has to.
         const int variant = scan_variant(g);
-        for (int strict = 0; strict < 2; strict++) {
-            const size_t lds = trace_lds_bytes(variant, strict != 0, n_pad, ntiles);
-            for (int mode = 0; mode < 2; mode++)
-                HIP_TRY(strict ? prepare_trace_strict(g.launch, mode, variant, lds) : prepare_trace_fast(g.launch, mode, variant, lds));
-            (void)(strict ? trace_blocks_per_cu_strict(g.launch, variant, lds) : trace_blocks_per_cu_fast(g.launch, variant, lds));
+        for (int build = 0; build < kBuilds; build++) {
+            const size_t lds = trace_lds_bytes(variant, reference_arithmetic(build), n_pad, ntiles);
+            for (int mode = 0; mode < 2; mode++) HIP_TRY(prepare_trace(g.launch, build, mode, variant, lds));
+            (void)trace_blocks_per_cu(g.launch, build, variant, lds);
         }
     }
     return RT_OK;

@@ -1,5 +1,5 @@
-// Shared declarations between the host side of librtmi.so (rt_api.hip) and its two
-// kernel translation units (rt_trace_strict.hip, rt_trace_fast.hip).
+// Shared declarations between the host side of librtmi.so (rt_api.hip) and its three
+// kernel translation units (rt_trace_exact.hip, rt_trace_strict.hip, rt_trace_fast.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -134,16 +134,20 @@ __host__ __device__ inline uint32_t part_row_at(uint32_t k, int tile_rows, int p
     return (t * (uint32_t)part_count + (uint32_t)part_index) * tr + r;
 }
 
+// The three builds of the path-tracing kernel (rt_opts.build): each is a translation unit of its own.
+enum { kBuildExact = 0, kBuildStrict = 1, kBuildFast = 2, kBuilds = 3 };
+constexpr bool reference_arithmetic(int build) { return build != kBuildFast; }
+
 // The dynamic-LDS attribute and the occupancy answer depend only on (device, kernel, LDS bytes):
 // each device context looks them up once per change of scene size, not once per frame.
 struct LaunchCache {
-    size_t attr_lds[2][2][kScanVariants];     // [build][mode][variant]: LDS size the attribute was last set to
-    size_t occ_lds[2][kScanVariants];         // [build][variant]
-    int occ_blocks[2][kScanVariants];
+    size_t attr_lds[kBuilds][2][kScanVariants];     // [build][mode][variant]: LDS size the attribute was last set to
+    size_t occ_lds[kBuilds][kScanVariants];         // [build][variant]
+    int occ_blocks[kBuilds][kScanVariants];
     LaunchCache() { reset(); }
     void reset()
     {
-        for (int b = 0; b < 2; b++)
+        for (int b = 0; b < kBuilds; b++)
             for (int g = 0; g < kScanVariants; g++) {
                 occ_lds[b][g] = (size_t)-1; occ_blocks[b][g] = 1;
                 for (int m = 0; m < 2; m++) attr_lds[b][m][g] = (size_t)-1;
@@ -151,19 +155,16 @@ struct LaunchCache {
     }
 };
 
-hipError_t launch_trace_strict(LaunchCache &c, const TraceParams &p, int variant, int blocks, size_t lds_bytes, hipStream_t s);
-hipError_t launch_trace_fast(LaunchCache &c, const TraceParams &p, int variant, int blocks, size_t lds_bytes, hipStream_t s);
+// The kernel instantiation of a build for (mode, variant): one function per translation unit.
+typedef void (*trace_fn)(const TraceParams);
+trace_fn trace_kernel_exact(int mode, int variant);
+trace_fn trace_kernel_strict(int mode, int variant);
+trace_fn trace_kernel_fast(int mode, int variant);
 hipError_t launch_resolve(const ResolveParams &p, hipStream_t s);
-// Sets the dynamic-LDS attribute of the kernel instantiation (mode, variant) if it differs from
-// the cached one; the first call per instantiation also makes the runtime load its code object.
-hipError_t prepare_trace_strict(LaunchCache &c, int mode, int variant, size_t lds_bytes);
-hipError_t prepare_trace_fast(LaunchCache &c, int mode, int variant, size_t lds_bytes);
-int trace_blocks_per_cu_strict(LaunchCache &c, int variant, size_t lds_bytes);
-int trace_blocks_per_cu_fast(LaunchCache &c, int variant, size_t lds_bytes);
 
 // Dynamic LDS of a trace kernel: [matrix image][geometry image][caller's indices][wave regions] (matrix scan),
 // [geometry image][candidate queues] (vector scan).
-inline size_t trace_lds_bytes(int variant, bool strict, int n_pad, int ntiles)
+inline size_t trace_lds_bytes(int variant, bool strict, int n_pad, int ntiles)     // strict: reference_arithmetic(build)
 {
     if (variant == kScanMatrixGlobal) return (size_t)(kMatBlockThreads / 64) * kMatWaveBytes;
     if (variant == kScanMatrix) return matrix_lds_bytes(n_pad, ntiles);

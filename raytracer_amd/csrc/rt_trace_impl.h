@@ -1,7 +1,10 @@
-// Path-tracing kernel body, compiled twice:
-//   rt_trace_strict.hip : RT_STRICT 1, -ffp-contract=off, IEEE sqrt and divide.  Every f32
-//                         operation is written in the order the reference writes it, so the
-//                         image is bit-identical to a CPU evaluation of the same expressions.
+// Path-tracing kernel body, compiled three times:
+//   rt_trace_exact.hip  : RT_STRICT 1, RT_DIRECT 1, -ffp-contract=off, IEEE sqrt and divide.  Every f32
+//                         operation of the path is written in the order the reference writes it; the
+//                         reference's rejection samplers are replaced by loop-free maps a CPU reproduces
+//                         bit for bit.  The default build.
+//   rt_trace_strict.hip : RT_STRICT 1, the same arithmetic with the reference's rejection samplers and
+//                         the reference's order of random draws.
 //   rt_trace_fast.hip   : RT_STRICT 0, FMA contraction, unit-length ray directions, hardware
 //                         rsqrt/rcp.  Same estimator, not bit-identical.
 //
@@ -19,8 +22,11 @@
 //   vec3f_* src/util.c:83-220.
 #include "rt_device.h"
 
-#ifndef RT_STRICT
-#error "RT_STRICT must be defined"
+#if !defined(RT_STRICT) || !defined(RT_NS) || !defined(RT_KERNEL_FOR)
+#error "RT_STRICT, RT_NS and RT_KERNEL_FOR must be defined"
+#endif
+#ifndef RT_DIRECT
+#define RT_DIRECT 0         // 1 (with RT_STRICT): loop-free samplers in place of the reference's rejection loops
 #endif
 
 
@@ -154,6 +160,75 @@ __device__ __forceinline__ V3 refract(V3 v, V3 n, float e)
     V3 par = scale(n, -1.0f * rt_sqrt(fabsf(1.0f - lensq(perp))));
     return add(perp, par);
 }
+
+#if RT_STRICT && RT_DIRECT
+// Exact build: the reference's rejection samplers (util.c:170-200) are replaced by loop-free maps with the same
+// distributions, written so that a CPU evaluates them to the same bits: integer arithmetic on the 32-bit draw,
+// conversions and scalings that are exact in f32, IEEE square root, and polynomials whose every step is either a
+// single rounded operation or an explicit fused multiply-add (fmaf on the CPU side).  One draw gives two 16-bit
+// fields (hi, lo); a field k stands for the centre of its stratum, (k + 0.5) / 65536.
+// In constant-u mode the reference's loops reject u = 0.5 a hundred times and return the zero vector.
+
+// cos and sin of 2 pi i / 65536.  The nearest quarter turn q is taken off in integers, which leaves an angle
+// within +-pi/4 for the two polynomials (the single-precision kernels of the Cephes library, about one ulp), and
+// the quarter turns are put back by swapping and negating.
+__device__ __forceinline__ void sincos_turns16(uint32_t i, float &c, float &s)
+{
+    const uint32_t q = (i + 8192U) >> 14;                                  // 0 .. 4
+    const float th = (float)((int)i - (int)(q << 14)) * 9.58737992428525768e-5f;   // * 2 pi / 65536
+    const float z = th * th;
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    const float s0 = fmaf(ps * z, th, th);
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    const float c0 = fmaf(pc, z * z, fmaf(-0.5f, z, 1.0f));
+    const bool swap = (q & 1U) != 0U;
+    const float c1 = swap ? s0 : c0, s1 = swap ? c0 : s0;
+    c = __uint_as_float(__float_as_uint(c1) ^ (((q + 1U) & 2U) << 30));    // quarter turns 1 and 2: cos changes sign
+    s = __uint_as_float(__float_as_uint(s1) ^ ((q & 2U) << 30));           // quarter turns 2 and 3: sin changes sign
+}
+
+// sample_square (Main.c:764-768) from one draw: offsets (k + 0.5) / 65536 - 0.5
+template <int MODE>
+__device__ __forceinline__ void jitter_direct(Rng &r, float &offx, float &offy)
+{
+    if (MODE == 1) { offx = 0.0f; offy = 0.0f; return; }
+    const uint32_t x = mix32(r.ctr);
+    r.ctr += 0x9E3779B9U;
+    const float bias = -0.5f + 1.0f / 131072.0f;
+    offx = fmaf((float)(x >> 16), 1.0f / 65536.0f, bias);
+    offy = fmaf((float)(x & 0xffffU), 1.0f / 65536.0f, bias);
+}
+
+// uniform on the unit sphere (replaces vec3f_random_direction, util.c:170-184): z uniform in (-1, 1), azimuth uniform
+template <int MODE>
+__device__ __forceinline__ V3 sphere_direction_direct(Rng &r)
+{
+    if (MODE == 1) return v3(0.0f, 0.0f, 0.0f);
+    const uint32_t x = mix32(r.ctr);
+    r.ctr += 0x9E3779B9U;
+    const float z = fmaf((float)(x >> 16), -1.0f / 32768.0f, 65535.0f / 65536.0f);   // (65535 - 2 k) / 65536, exact
+    const float rad = rt_sqrt(fmaf(-z, z, 1.0f));
+    float c, s;
+    sincos_turns16(x & 0xffffU, c, s);
+    return v3(rad * c, rad * s, z);
+}
+
+// uniform in the unit disk (replaces vec3f_random_direction_2d, util.c:186-200): radius sqrt(u), azimuth uniform
+template <int MODE>
+__device__ __forceinline__ void disk_point_direct(Rng &r, float &px, float &py)
+{
+    if (MODE == 1) { px = 0.0f; py = 0.0f; return; }
+    const uint32_t x = mix32(r.ctr);
+    r.ctr += 0x9E3779B9U;
+    const float rad = rt_sqrt(fmaf((float)(x >> 16), 1.0f / 65536.0f, 1.0f / 131072.0f));    // (k + 0.5) / 65536, exact
+    float c, s;
+    sincos_turns16(x & 0xffffU, c, s);
+    px = rad * c;
+    py = rad * s;
+}
+#endif   // RT_STRICT && RT_DIRECT
 
 #if !RT_STRICT
 // Fast build: the reference's rejection samplers (util.c:170-200) are replaced by direct maps
@@ -763,7 +838,10 @@ template <int MODE>
 __device__ __forceinline__ void camera_ray(const TraceParams &p, Lane &L)
 {
     const Camera &c = p.cam;
-#if RT_STRICT
+#if RT_STRICT && RT_DIRECT
+    float offx, offy;
+    jitter_direct<MODE>(L.rng, offx, offy);
+#elif RT_STRICT
     float offx = rng_float<MODE>(L.rng) - 0.5f;
     float offy = rng_float<MODE>(L.rng) - 0.5f;
 #else
@@ -779,7 +857,10 @@ __device__ __forceinline__ void camera_ray(const TraceParams &p, Lane &L)
     ps.z = c.p00[2] + (fx * c.du[2]) + (fy * c.dv[2]);
     V3 org = v3(c.pos[0], c.pos[1], c.pos[2]);
     if (!(c.defocus_angle <= 0.0f)) {
-#if RT_STRICT
+#if RT_STRICT && RT_DIRECT
+        V3 q = v3(0.0f, 0.0f, 0.0f);
+        disk_point_direct<MODE>(L.rng, q.x, q.y);
+#elif RT_STRICT
         V3 q = random_direction_2d<MODE>(L.rng);
 #else
         V3 q = v3(0.0f, 0.0f, 0.0f);
@@ -1041,7 +1122,11 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
                 mtype = __float_as_int(mB.y);
             }
             V3 rd = v3(0.0f, 0.0f, 0.0f);
+#if RT_DIRECT
+            if (mtype == 0 || mtype == 1) rd = sphere_direction_direct<MODE>(L.rng);
+#else
             if (mtype == 0 || mtype == 1) rd = random_direction<MODE>(L.rng);
+#endif
             V3 normed = v3(0.0f, 0.0f, 0.0f);
             if (mtype != 0) normed = unit(mtype == 1 ? reflect(L.d, n) : L.d);
             if (hit >= 0) {
@@ -1175,4 +1260,14 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
 }
 
 }  // namespace RT_NS
+
+// The instantiation for (mode, variant); RT_KERNEL_FOR names this build's selector (rt_device.h).
+trace_fn RT_KERNEL_FOR(int mode, int variant)
+{
+    if (variant == kScanMatrix) return mode == 1 ? RT_NS::trace_kernel<1, kScanMatrix> : RT_NS::trace_kernel<0, kScanMatrix>;
+    if (variant == kScanMatrixGlobal) return mode == 1 ? RT_NS::trace_kernel<1, kScanMatrixGlobal> : RT_NS::trace_kernel<0, kScanMatrixGlobal>;
+    if (variant == kScanVectorGlobal) return mode == 1 ? RT_NS::trace_kernel<1, kScanVectorGlobal> : RT_NS::trace_kernel<0, kScanVectorGlobal>;
+    return mode == 1 ? RT_NS::trace_kernel<1, kScanVectorLds> : RT_NS::trace_kernel<0, kScanVectorLds>;
+}
+
 }  // namespace rtmi

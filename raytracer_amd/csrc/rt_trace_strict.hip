@@ -1,9 +1,11 @@
 // Strict build of the path-tracing kernel: no FMA contraction (this file is compiled with
-// -ffp-contract=off), IEEE-rounded sqrt and divide.  Also holds the resolve kernel, whose
+// -ffp-contract=off), IEEE-rounded sqrt and divide, the reference's rejection samplers with the
+// reference's order of random draws.  Also holds the resolve kernel, whose
 // arithmetic (chunk sums, 1/spp scale, gamma, quantisation) must round exactly as
 // render_tile / linear_to_gamma / to_color4 do (Main.c:975-979, src/base_graphics.c:11-30).
 #define RT_STRICT 1
 #define RT_NS strict_build
+#define RT_KERNEL_FOR trace_kernel_strict
 #include "rt_trace_impl.h"
 
 namespace rtmi {
@@ -47,47 +49,6 @@ hipError_t launch_resolve(const ResolveParams &p, hipStream_t s)
     const int blocks = (int)((p.npix + threads - 1) / threads);
     hipLaunchKernelGGL(resolve_kernel, dim3(blocks), dim3(threads), 0, s, p);
     return hipGetLastError();
-}
-
-typedef void (*trace_fn)(const TraceParams);
-
-static trace_fn kernel_for(int mode, int variant)
-{
-    if (variant == kScanMatrix) return mode ? strict_build::trace_kernel<1, kScanMatrix> : strict_build::trace_kernel<0, kScanMatrix>;
-    if (variant == kScanMatrixGlobal) return mode ? strict_build::trace_kernel<1, kScanMatrixGlobal> : strict_build::trace_kernel<0, kScanMatrixGlobal>;
-    if (variant == kScanVectorGlobal) return mode ? strict_build::trace_kernel<1, kScanVectorGlobal> : strict_build::trace_kernel<0, kScanVectorGlobal>;
-    return mode ? strict_build::trace_kernel<1, kScanVectorLds> : strict_build::trace_kernel<0, kScanVectorLds>;
-}
-
-hipError_t prepare_trace_strict(LaunchCache &c, int mode, int variant, size_t lds_bytes)
-{
-    mode = mode == 1 ? 1 : 0;
-    if (c.attr_lds[0][mode][variant] == lds_bytes) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute((const void *)kernel_for(mode, variant),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e == hipSuccess) c.attr_lds[0][mode][variant] = lds_bytes;
-    return e;
-}
-
-hipError_t launch_trace_strict(LaunchCache &c, const TraceParams &p, int variant, int blocks, size_t lds_bytes, hipStream_t s)
-{
-    const int mode = p.mode == 1 ? 1 : 0;
-    hipError_t e = prepare_trace_strict(c, mode, variant, lds_bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel_for(mode, variant), dim3(blocks), dim3(block_threads_of(variant)), lds_bytes, s, p);
-    return hipGetLastError();
-}
-
-int trace_blocks_per_cu_strict(LaunchCache &c, int variant, size_t lds_bytes)
-{
-    if (c.occ_lds[0][variant] == lds_bytes) return c.occ_blocks[0][variant];
-    int n = 0;
-    if (prepare_trace_strict(c, 0, variant, lds_bytes) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel_for(0, variant), block_threads_of(variant), lds_bytes) != hipSuccess)
-        return 1;
-    c.occ_lds[0][variant] = lds_bytes;
-    c.occ_blocks[0][variant] = n > 0 ? n : 1;
-    return c.occ_blocks[0][variant];
 }
 
 }  // namespace rtmi

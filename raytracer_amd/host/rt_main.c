@@ -5,7 +5,7 @@
  * a caller-owned RGBA8 buffer, then write the buffer out.
  *
  *   rt_main (--scene spheres.bin | --generate HALF) [--width 400] [--spp 10] [--depth 20] [--out frame.ppm|.tga]
- *           [--strict] [--const-u] [--seed N] [--chunk N] [--device N | --devices 0,1,...] [--frames N]
+ *           [--strict | --fast] [--const-u] [--seed N] [--chunk N] [--device N | --devices 0,1,...] [--frames N]
  *
  * --generate HALF builds the scene with rt_scene_generate (init_scene with its random block over
  * [-HALF, HALF)^2; 11 = the reference's final scene, 0 = its shipped three-sphere scene).
@@ -64,7 +64,8 @@ int main(int argc, char **argv)
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
         const char *v = (i + 1 < argc) ? argv[i + 1] : NULL;
-        if (!strcmp(a, "--strict")) o.strict_fp = 1;
+        if (!strcmp(a, "--strict")) o.build = RT_BUILD_STRICT;
+        else if (!strcmp(a, "--fast")) o.build = RT_BUILD_FAST;
         else if (!strcmp(a, "--const-u")) o.mode = RT_MODE_CONST_U;
         else if (!v) { fprintf(stderr, "rt_main: %s needs a value\n", a); return 2; }
         else if (!strcmp(a, "--scene")) { scene = v; i++; }

@@ -39,15 +39,15 @@ def main():
             sph = ss.random_scene(kind)
             W, H, spp, depth = 320, 180, 6, 12
         rt.set_world(sph)
-        for strict in (False, True):
+        for build in ("exact", "strict", "fast"):
             for mode in (rt.MODE_MC, rt.MODE_CONST_U):
                 if kind is not None:
                     cam = rt.camera(W, H, ss.view_params(rt, kind, defocus_angle=0.6 if mode == rt.MODE_MC else 0.0))
-                r = rt.render(cam, W, H, spp if mode == rt.MODE_MC else 1, depth, mode=mode, strict_fp=strict,
+                r = rt.render(cam, W, H, spp if mode == rt.MODE_MC else 1, depth, mode=mode, build=build,
                               seed=7, chunk_spp=2, want_hit=True)
                 c = (C.c_ulonglong * 16)()
                 L.rt_diag_counters(c, 16)
-                print(json.dumps({"scene": name, "strict": strict, "mode": mode, "rays": int(c[1]), "wave_scans": int(c[5]),
+                print(json.dumps({"scene": name, "build": build, "mode": mode, "rays": int(c[1]), "wave_scans": int(c[5]),
                                   "queued": int(c[3]), "lost_hits": int(c[8]),
                                   "seen": float((r["hit"] >= 0).mean())}), flush=True)
     rt.shutdown()

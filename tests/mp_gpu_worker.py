@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
-    out_path, strict = sys.argv[1], int(sys.argv[2])
+    out_path, build = sys.argv[1], int(sys.argv[2])
     import raytracer_amd as rt
     from raytracer_amd.multigpu import RowGather, weighted_row_maps
     from conftest import load_scene
@@ -34,7 +34,7 @@ def main():
     rows = weighted_row_maps(H, 8, speed.tolist())
     rg = RowGather(rows, W, 4, torch.uint8, dev, rank, world, via_host=True)
     for _ in range(2):                                      # second call reuses every buffer
-        rt.render_device(cam, rg.mine.data_ptr(), W, H, 6, 8, strict_fp=bool(strict), seed=3, chunk_spp=4,
+        rt.render_device(cam, rg.mine.data_ptr(), W, H, 6, 8, build=build, seed=3, chunk_spp=4,
                          rows=rows[rank])
         full = rg.gather()
     dist.barrier()

@@ -1,5 +1,5 @@
-"""Worker of test_gpu_parity.py::test_every_scan_variant_gives_the_same_image: renders a few scenes with the
-strict and the fast build and writes hit indices, accumulators and ray counts to an .npz file.  The test
+"""Worker of test_gpu_parity.py::test_every_scan_variant_gives_the_same_image: renders a few scenes with
+every build and writes hit indices, accumulators and ray counts to an .npz file.  The test
 runs it once as is, once with RTMI_SCAN=vector (packed-FP32 scan for every scene size) and with RTMI_ORDER=caller
 (spheres kept in the caller's order on the device)."""
 import os
@@ -25,10 +25,10 @@ def main(out_path):
     cam = rt.camera(W, H, p)
     for n, seed in ((40, 1), (600, 2), (1300, 3), (5000, 4)):
         rt.set_world(_tie_scene(n, seed))
-        for strict in (True, False):
+        for build in ("exact", "strict", "fast"):
             for rep in range(2):                       # twice: the image must not change from run to run
-                r = rt.render(cam, W, H, 4, 20, strict_fp=strict, seed=5, chunk_spp=2, want_hit=True, want_accum=True)
-                key = "n%d_%s_%d" % (n, "strict" if strict else "fast", rep)
+                r = rt.render(cam, W, H, 4, 20, build=build, seed=5, chunk_spp=2, want_hit=True, want_accum=True)
+                key = "n%d_%s_%d" % (n, build, rep)
                 out[key + "_hit"] = r["hit"].copy()
                 out[key + "_accum"] = r["accum"].copy()
                 out[key + "_rays"] = np.array([int(r["stats"].rays)], dtype=np.int64)

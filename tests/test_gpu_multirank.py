@@ -24,19 +24,19 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("strict", [1, 0])
-def test_three_ranks_one_gpu(rt, tmp_path, strict):
+@pytest.mark.parametrize("build", [0, 1, 2])
+def test_three_ranks_one_gpu(rt, tmp_path, build):
     out = str(tmp_path / "full.npy")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "mp_gpu_worker.py"), out, str(strict)]
+           os.path.join(ROOT, "tests", "mp_gpu_worker.py"), out, str(build)]
     subprocess.run(cmd, check=True, timeout=240, cwd=ROOT)
     got = np.load(out)
     counts = np.load(out + ".counts.npy")
     assert counts.sum() == got.shape[0] and counts[2] > counts[0]          # the deal followed the weights
     rt.set_world(load_scene("sf"))
     W, H = 200, rt.height_for(200)
-    ref = rt.render(rt.camera(W, H), W, H, 6, 8, strict_fp=bool(strict), seed=3, chunk_spp=4)["rgba"]
+    ref = rt.render(rt.camera(W, H), W, H, 6, 8, build=build, seed=3, chunk_spp=4)["rgba"]
     assert np.array_equal(got, ref)
 
 
@@ -54,8 +54,8 @@ def test_bench_two_ranks_one_gpu(tmp_path):
     assert out["roofline"]["frac"] > 0
 
 
-@pytest.mark.parametrize("strict", [True, False])
-def test_several_contexts_in_one_process(rt, strict):
+@pytest.mark.parametrize("build", ["exact", "strict", "fast"])
+def test_several_contexts_in_one_process(rt, build):
     """rt_init_devices: three contexts (sharing the one device of the test box) split a frame by
     rows, one host thread each.  Image, accumulators, hit indices and ray counts equal the
     single-context call; the deal adapts between frames without changing the image."""
@@ -64,31 +64,31 @@ def test_several_contexts_in_one_process(rt, strict):
     W, H = 240, m.height_for(240)
     rt.set_world(sph)
     cam = rt.camera(W, H)
-    one = rt.render(cam, W, H, 5, 20, strict_fp=strict, seed=9, chunk_spp=2, want_hit=True, want_accum=True)
+    one = rt.render(cam, W, H, 5, 20, build=build, seed=9, chunk_spp=2, want_hit=True, want_accum=True)
     try:
         m.init_devices([0, 0, 0])
         m.set_world(sph)
         for frame in range(3):                                    # later frames use measured speeds
-            many = m.render(cam, W, H, 5, 20, strict_fp=strict, seed=9, chunk_spp=2, want_hit=True, want_accum=True)
+            many = m.render(cam, W, H, 5, 20, build=build, seed=9, chunk_spp=2, want_hit=True, want_accum=True)
             assert np.array_equal(many["rgba"], one["rgba"])
             assert np.array_equal(many["accum"], one["accum"]) and np.array_equal(many["hit"], one["hit"])
             assert int(many["stats"].rays) == int(one["stats"].rays)
             assert int(many["stats"].samples) == W * H * 5
         # a caller's own partition is split further, not overridden
         part = np.zeros((H, W, 4), np.uint8)
-        m.render(cam, W, H, 5, 20, strict_fp=strict, seed=9, chunk_spp=2, part_index=1, part_count=2, out=part)
+        m.render(cam, W, H, 5, 20, build=build, seed=9, chunk_spp=2, part_index=1, part_count=2, out=part)
         rows = m.part_row_map(H, 16, 1, 2)
         assert np.array_equal(part[rows], one["rgba"][rows])
         other = np.setdiff1d(np.arange(H), rows)
         assert not part[other].any()
         # fewer tiles than contexts: two rows in all
         tiny = np.zeros((H, W, 4), np.uint8)
-        m.render(cam, W, H, 5, 20, strict_fp=strict, seed=9, chunk_spp=2, rows=[7, 100], out=tiny)
+        m.render(cam, W, H, 5, 20, build=build, seed=9, chunk_spp=2, rows=[7, 100], out=tiny)
         assert np.array_equal(tiny[[7, 100]], one["rgba"][[7, 100]]) and not tiny[:7].any()
         # progressive frames over several contexts: the running sums stay with the rows' owners
         for f in range(3):
-            prog = m.render_progressive(cam, W, H, 2, 20, f, strict_fp=strict, seed=9, chunk_spp=2, want_accum=True)
-        six = rt.render(cam, W, H, 6, 20, strict_fp=strict, seed=9, chunk_spp=2, want_accum=True)
+            prog = m.render_progressive(cam, W, H, 2, 20, f, build=build, seed=9, chunk_spp=2, want_accum=True)
+        six = rt.render(cam, W, H, 6, 20, build=build, seed=9, chunk_spp=2, want_accum=True)
         assert np.array_equal(prog["rgba"], six["rgba"]) and np.array_equal(prog["accum"], six["accum"])
         with pytest.raises(m.RtError, match="one device"):
             m.render_device(cam, 0, W, H, 1, 5)

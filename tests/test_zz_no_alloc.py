@@ -33,14 +33,14 @@ def _same(a, b):
     assert a[3:] == b[3:] and a[3] > 0
 
 
-@pytest.mark.parametrize("strict", [True, False])
-def test_no_alloc_entry_point_matches_the_allocating_one(rt, strict):
+@pytest.mark.parametrize("build", ["exact", "strict", "fast"])
+def test_no_alloc_entry_point_matches_the_allocating_one(rt, build):
     sph = load_scene("sf")
     rt.set_world(sph)
     # first call: 640x360, three chunks per pixel (11 MB of per-chunk sums in the scratch array)
     W, H = 640, rt.height_for(640)
     cam = rt.camera(W, H)
-    ref, got = _both(rt, torch, cam, W, H, 6, 50, strict_fp=strict, seed=5, chunk_spp=2)
+    ref, got = _both(rt, torch, cam, W, H, 6, 50, build=build, seed=5, chunk_spp=2)
     _same(ref, got)
     assert (got[0][..., 3] == 255).all() and (got[2] >= -1).all()
     # second call, smaller input: 200x112, one part of three, other seed; the array keeps the first
@@ -48,15 +48,15 @@ def test_no_alloc_entry_point_matches_the_allocating_one(rt, strict):
     free0 = torch.cuda.mem_get_info()[0]
     W2, H2 = 200, rt.height_for(200)
     cam2 = rt.camera(W2, H2)
-    ref2, got2 = _both(rt, torch, cam2, W2, H2, 5, 20, strict_fp=strict, seed=9, chunk_spp=0,
+    ref2, got2 = _both(rt, torch, cam2, W2, H2, 5, 20, build=build, seed=9, chunk_spp=0,
                        tile_rows=8, part_index=1, part_count=3)
     _same(ref2, got2)
     # and the first again: nothing of the smaller call is left over
-    ref3, got3 = _both(rt, torch, cam, W, H, 6, 50, strict_fp=strict, seed=5, chunk_spp=2)
+    ref3, got3 = _both(rt, torch, cam, W, H, 6, 50, build=build, seed=5, chunk_spp=2)
     _same(ref, got3)
     # constant-u mode and depth 0 take the same path
-    _same(*_both(rt, torch, cam2, W2, H2, 1, 50, strict_fp=strict, mode=rt.MODE_CONST_U, chunk_spp=0))
-    a, b = _both(rt, torch, cam2, W2, H2, 2, 0, strict_fp=strict, chunk_spp=0)
+    _same(*_both(rt, torch, cam2, W2, H2, 1, 50, build=build, mode=rt.MODE_CONST_U, chunk_spp=0))
+    a, b = _both(rt, torch, cam2, W2, H2, 2, 0, build=build, chunk_spp=0)
     assert np.array_equal(a[0], b[0]) and (b[0][..., :3] == 0).all()
     free1 = torch.cuda.mem_get_info()[0]
     assert free1 >= free0            # torch's own caching allocator served the test's tensors from its pool
