@@ -551,6 +551,9 @@ int refcpu_render(const rt_camera *cam, const rt_sphere *spheres, size_t count,
         opts->stats->samples = rows * width * (uint64_t)spp;
         opts->stats->rays = p.rays;
         opts->stats->sphere_tests = p.rays * (uint64_t)count;
+        opts->stats->chunk_spp = (uint32_t)(opts->chunk_spp > 0 && opts->chunk_spp < spp ? opts->chunk_spp : spp);
+        opts->stats->scan_tiles = 0;
+        opts->stats->wave_scans = 0;
         opts->stats->kernel_ms = 0.0;
         opts->stats->resolve_ms = 0.0;
         opts->stats->total_ms = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;

@@ -35,7 +35,7 @@ static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES]
 
 namespace {
 
-constexpr int kCounters = 20;                    // 64-bit words: [0] next work unit, [1] rays cast, the rest diagnostics
+constexpr int kCounters = 20;                    // 64-bit words: [0] next work unit, [1] rays cast, [19] wave scans, the rest diagnostics
 constexpr size_t kScratchCountersBytes = 256;
 constexpr size_t kScratchPartialBytes = (size_t)RT_NOALLOC_SCRATCH_BYTES - kScratchCountersBytes;
 constexpr uint32_t kProgBroken = 0xffffffffu;    // prog_frames of a sequence that must restart at frame 0
@@ -84,9 +84,6 @@ struct Ctx {
     uint32_t prog_w = 0, prog_h = 0, prog_npix = 0, prog_frames = kProgBroken;
     int prog_spp = 0, prog_chunk = 0;
     std::vector<uint32_t> prog_rows;        // image row of every owned row of the sequence, in buffer order
-    std::vector<uint8_t> h_rgba;
-    std::vector<float> h_accum;
-    std::vector<int32_t> h_hit;
     unsigned long long last_counters[kCounters] = {0};
 };
 
@@ -211,13 +208,17 @@ inline float deg_to_rad(float v) { return turns_to_rad(v / 360.f); }
 // assembled image to equal the single-device image.
 // Short units keep the end of a launch, when units run out and lanes fall idle, short; each halving
 // of the unit below 8 samples costs about 0.7 % in unit hand-outs, so only images that give a lane of
-// a full MI355X (256 CUs x 2048 lanes) fewer than 128 eight-sample units get shorter ones.  The
-// per-chunk sums of the full image are capped at 16 GiB.
+// a full MI355X (256 CUs x 2048 lanes) fewer than 128 eight-sample units get shorter ones.  Every unit
+// writes one 16-byte partial sum that the resolve kernel reads back, so the unit grows with the work:
+// the per-chunk sums of the full image stay below 2 GiB (3840x2160 at 1000 spp: 63 samples per unit,
+// 16 chunks, 2.1 GB; with 8 samples per unit it was 16.6 GB of HBM held and written for nothing: a
+// launch with that many units loses nothing to longer ones, measured 230.7 / 229.4 / 229.3 / 228.7 ms
+// at 4 / 8 / 16 / 32 samples per unit on 3840x2160 at 250 spp).
 int resolve_chunk(int chunk_opt, uint32_t width, uint32_t height, int spp, bool progressive)
 {
     if (chunk_opt != RT_CHUNK_AUTO) return (chunk_opt > 0 && chunk_opt < spp) ? chunk_opt : spp;
     const uint64_t full = (uint64_t)width * (uint64_t)height;
-    const uint64_t max_chunks = std::max<uint64_t>(1, (16ULL << 30) / (std::max<uint64_t>(full, 1) * sizeof(float4)));
+    const uint64_t max_chunks = std::max<uint64_t>(1, (2ULL << 30) / (std::max<uint64_t>(full, 1) * sizeof(float4)));
     const uint64_t least = ((uint64_t)spp + max_chunks - 1) / max_chunks;
     const uint64_t lanes = 256ULL * 2048ULL;
     const uint64_t small = std::max<uint64_t>(1, full * (uint64_t)spp / (128 * lanes));
@@ -226,12 +227,13 @@ int resolve_chunk(int chunk_opt, uint32_t width, uint32_t height, int spp, bool 
     return chunk;
 }
 
-int scan_variant(const Ctx &g)
+int scan_variant(int n, int n_pad, int ntiles)
 {
-    if (g.ntiles > 0 && !g_vector_scan)
-        return (g.ntiles <= kMaxTilesMatrix && matrix_lds_bytes(g.n_pad, g.ntiles) <= (size_t)kLdsBytes) ? kScanMatrix : kScanMatrixGlobal;
-    return g.n > kMaxSpheresLds ? kScanVectorGlobal : kScanVectorLds;
+    if (ntiles > 0 && !g_vector_scan)
+        return (ntiles <= kMaxTilesMatrix && matrix_lds_bytes(n_pad, ntiles) <= (size_t)kLdsBytes) ? kScanMatrix : kScanMatrixGlobal;
+    return n > kMaxSpheresLds ? kScanVectorGlobal : kScanVectorLds;
 }
+int scan_variant(const Ctx &g) { return scan_variant(g.n, g.n_pad, g.ntiles); }
 
 trace_fn kernel_of(int build, int mode, int variant)
 {
@@ -478,34 +480,24 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
     }
 
     // read back (host-pointer entry) and/or wait
-    // A frame that owns all rows is copied straight into the caller's buffer: by the DMA engine if
-    // the buffer came from rt_host_alloc, staged by the runtime otherwise.
-    const bool whole_image = !device_ptrs && !explicit_rows && part_count == 1 && npix > 0;
-    if (whole_image) HIP_TRY(hipMemcpyAsync(rgba, d_rgba, (size_t)npix * 4, hipMemcpyDeviceToHost, g.stream));
+    // The owned rows sit compactly in the device buffers; every run of consecutive image rows (the whole
+    // image for an undivided frame, one row tile of a part otherwise) is copied straight to its place in
+    // the caller's buffers, with no staging copy on the host in between: by the DMA engine if the buffer
+    // came from rt_host_alloc, staged by the runtime otherwise.
     if (!device_ptrs && npix > 0) {
-        if (!whole_image) {
-            g.h_rgba.resize((size_t)npix * 4);
-            HIP_TRY(hipMemcpyAsync(g.h_rgba.data(), d_rgba, (size_t)npix * 4, hipMemcpyDeviceToHost, g.stream));
-        }
-        if (o.accum_out) {
-            g.h_accum.resize((size_t)npix * 3);
-            HIP_TRY(hipMemcpyAsync(g.h_accum.data(), d_accum, (size_t)npix * 12, hipMemcpyDeviceToHost, g.stream));
-        }
-        if (o.hit_index_out) {
-            g.h_hit.resize(npix);
-            HIP_TRY(hipMemcpyAsync(g.h_hit.data(), d_hit, (size_t)npix * 4, hipMemcpyDeviceToHost, g.stream));
+        uint32_t k0 = 0;
+        while (k0 < rows) {
+            const uint32_t y0 = explicit_rows ? o.rows[k0] : rt_part_row_at(k0, tile_rows, part_index, part_count);
+            uint32_t k1 = k0 + 1;
+            while (k1 < rows && (explicit_rows ? o.rows[k1] : rt_part_row_at(k1, tile_rows, part_index, part_count)) == y0 + (k1 - k0)) k1++;
+            const size_t px0 = (size_t)k0 * width, at = (size_t)y0 * width, npx = (size_t)(k1 - k0) * width;
+            HIP_TRY(hipMemcpyAsync(rgba + at * 4, d_rgba + px0 * 4, npx * 4, hipMemcpyDeviceToHost, g.stream));
+            if (o.accum_out) HIP_TRY(hipMemcpyAsync(o.accum_out + at * 3, d_accum + px0 * 3, npx * 12, hipMemcpyDeviceToHost, g.stream));
+            if (o.hit_index_out) HIP_TRY(hipMemcpyAsync(o.hit_index_out + at, d_hit + px0, npx * 4, hipMemcpyDeviceToHost, g.stream));
+            k0 = k1;
         }
     }
     HIP_TRY(hipStreamSynchronize(g.stream));
-
-    if (!device_ptrs) {
-        for (uint32_t k = 0; k < rows; k++) {
-            const uint32_t y = explicit_rows ? o.rows[k] : rt_part_row_at(k, tile_rows, part_index, part_count);
-            if (!whole_image) memcpy(rgba + (size_t)y * width * 4, g.h_rgba.data() + (size_t)k * width * 4, (size_t)width * 4);
-            if (o.accum_out) memcpy(o.accum_out + (size_t)y * width * 3, g.h_accum.data() + (size_t)k * width * 3, (size_t)width * 12);
-            if (o.hit_index_out) memcpy(o.hit_index_out + (size_t)y * width, g.h_hit.data() + (size_t)k * width, (size_t)width * 4);
-        }
-    }
 
     if (progressive) g.prog_frames = frames_after;
 
@@ -516,6 +508,8 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             unsigned long long *c = g.last_counters;
             HIP_TRY(hipMemcpy(c, d_counters, sizeof g.last_counters, hipMemcpyDeviceToHost));
             st.rays = c[1];
+            st.wave_scans = c[19];
+            st.scan_tiles = is_matrix(scan_variant(g)) ? (uint32_t)g.ntiles : 0;
 #ifdef RT_DIAG
             fprintf(stderr, "diag: wave scans %llu; per wave scan: pair branches taken %.1f, filter passes %.1f, "
                     "queued candidates %.2f, drain iterations %.2f, live lanes %.1f; rays traced in shared-ray mode %llu of %llu; "
@@ -701,6 +695,7 @@ int render_on_all(const rt_camera *cam, uint8_t *rgba, uint32_t width, uint32_t 
     total.chunk_spp = (uint32_t)chunk;
     for (int i = 0; i < nc; i++) {
         total.samples += st[i].samples; total.rays += st[i].rays; total.sphere_tests += st[i].sphere_tests;
+        total.wave_scans += st[i].wave_scans; total.scan_tiles = std::max(total.scan_tiles, st[i].scan_tiles);
         total.kernel_ms = std::max(total.kernel_ms, st[i].kernel_ms);
         total.resolve_ms = std::max(total.resolve_ms, st[i].resolve_ms);
         if (st[i].kernel_ms > 0.0 && !rows[i].empty())
@@ -959,6 +954,10 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
                     for (int e = 0; e < 8; e++)
                         aimg[(((size_t)t * 2 + s2) * 64 + hh * 32 + row) * 8 + e] = ent[16 * s2 + 8 * hh + e];
         }
+    // Until every upload to every context has succeeded no context holds a world: a failure in between (out of
+    // memory on one device, say) must not leave new scalars next to old buffers, or some contexts on the new
+    // world and others on the old one; rt_render then reports RT_ERR_STATE until rt_set_world succeeds.
+    for (int k = 0; k < g_nctx; k++) { g_ctx[k].n_pad = 0; g_ctx[k].n = 0; }
     for (int k = 0; k < g_nctx; k++) {
         Ctx &g = g_ctx[k];
         HIP_TRY(hipSetDevice(g.device));
@@ -979,20 +978,19 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
         HIP_TRY(hipMemcpy(g.geom.p, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(g.matA.p, matA.data(), matA.size() * sizeof(float4), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(g.matB.p, matB.data(), matB.size() * sizeof(float4), hipMemcpyHostToDevice));
-        g.n = n;
-        g.n_pad = n_pad;
         g.nbig = nbig;
         memcpy(g.big, big, sizeof big);
         g.c_near = (float)c_near;
         // Look up the launch geometry of every build now (code objects load, LDS attributes are set,
         // occupancy is queried), so that no render call after this one has to.
-        const int variant = scan_variant(g);
+        const int variant = scan_variant(n, n_pad, ntiles);      // the context itself gets its sizes only at the end
         for (int build = 0; build < kBuilds; build++) {
             const size_t lds = trace_lds_bytes(variant, reference_arithmetic(build), n_pad, ntiles);
             for (int mode = 0; mode < 2; mode++) HIP_TRY(prepare_trace(g.launch, build, mode, variant, lds));
             (void)trace_blocks_per_cu(g.launch, build, variant, lds);
         }
     }
+    for (int k = 0; k < g_nctx; k++) { g_ctx[k].n = n; g_ctx[k].n_pad = n_pad; }
     return RT_OK;
 }
 

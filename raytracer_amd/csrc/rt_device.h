@@ -111,7 +111,7 @@ struct TraceParams {
     uint32_t seed, sample_base;
     float4 *partial;                       // [nchunks][npix] per-chunk colour sums
     int32_t *hit_index;                    // [npix] compact, or nullptr
-    unsigned long long *counters;          // [0] next work unit, [1] rays cast ([2..15]: diagnostic build)
+    unsigned long long *counters;          // [0] next work unit, [1] rays cast, [19] sphere scans run by the waves ([2..18]: diagnostic build)
     unsigned long long total_units;        // npix * nchunks
 };
 

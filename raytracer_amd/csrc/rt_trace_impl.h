@@ -932,6 +932,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
     bool need_unit = true;     // lane must pull a new work unit
     bool need_sample = true;   // lane must start a new sample
     uint32_t rays = 0;
+    uint32_t wave_scans = 0;   // times this wave ran the sphere scan (wave-uniform)
     const uint32_t waves_per_block = blockDim.x >> 6;
     const uint32_t pool_units = (uint32_t)p.pool_units;    // work units a wave takes from the global counter at a time
     const unsigned long long static_units = (unsigned long long)gridDim.x * waves_per_block * pool_units;
@@ -1049,8 +1050,11 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
             const float inv = (q.a > 0.0f) ? __builtin_amdgcn_rsqf(q.a) : 0.0f;
             const unsigned long long live = __ballot(active);
             if (__popcll(live) <= p.coop_max) shared_ray_hit(p, s_geom, lane, live, q);
-            else if (is_matrix(VARIANT)) scan_spheres_matrix(p, s_geom, s_aimg, s_orig16, pool, lane, q.dx * inv, q.dy * inv, q.dz * inv, q RT_DIAG_PASS);
-            else scan_spheres(p, s_geom, queue, lane, q.dx * inv, q.dy * inv, q.dz * inv, 7.6293945e-6f, q RT_DIAG_PASS);
+            else {
+                wave_scans++;
+                if (is_matrix(VARIANT)) scan_spheres_matrix(p, s_geom, s_aimg, s_orig16, pool, lane, q.dx * inv, q.dy * inv, q.dz * inv, q RT_DIAG_PASS);
+                else scan_spheres(p, s_geom, queue, lane, q.dx * inv, q.dy * inv, q.dz * inv, 7.6293945e-6f, q RT_DIAG_PASS);
+            }
             if (!(q.a > 0.0f)) {
                 // a zero or NaN direction gives the filter nothing to work with: test everything
                 q.closest = 3.402823466e+38f; q.hit = -1;
@@ -1060,8 +1064,11 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
 #else
         const unsigned long long live = __ballot(active);
         if (__popcll(live) <= p.coop_max) shared_ray_hit(p, s_geom, lane, live, q);
-        else if (is_matrix(VARIANT)) scan_spheres_matrix(p, s_geom, s_aimg, s_orig16, pool, lane, q.dx, q.dy, q.dz, q RT_DIAG_PASS);
-        else scan_spheres(p, s_geom, queue, lane, q.dx, q.dy, q.dz, 1.9073486e-6f, q RT_DIAG_PASS);   // 2^-19
+        else {
+            wave_scans++;
+            if (is_matrix(VARIANT)) scan_spheres_matrix(p, s_geom, s_aimg, s_orig16, pool, lane, q.dx, q.dy, q.dz, q RT_DIAG_PASS);
+            else scan_spheres(p, s_geom, queue, lane, q.dx, q.dy, q.dz, 1.9073486e-6f, q RT_DIAG_PASS);   // 2^-19
+        }
 #ifdef RT_DIAG
         if (__popcll(live) <= p.coop_max) dg.shared_rays += (uint32_t)__popcll(live); else dg.scan_lanes += (uint32_t)__popcll(live);
 #endif
@@ -1223,10 +1230,13 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
 #endif
     }
 
-    // ---- statistics: rays cast ---------------------------------------------------------
+    // ---- statistics: rays cast, sphere scans run by the waves ------------------------------
     unsigned long long r64 = rays;
     for (int off = 32; off > 0; off >>= 1) r64 += __shfl_down(r64, off);
-    if (__lane_id() == 0) atomicAdd(&p.counters[1], r64);
+    if (__lane_id() == 0) {
+        atomicAdd(&p.counters[1], r64);
+        atomicAdd(&p.counters[19], (unsigned long long)wave_scans);
+    }
 #ifdef RT_DIAG
     if (__lane_id() == 0) {
         atomicAdd(&p.counters[2], (unsigned long long)dg.branches);

@@ -51,7 +51,8 @@ def test_bench_two_ranks_one_gpu(tmp_path):
     line = [l for l in res.stdout.decode().splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["value"] > 0 and sum(out["config"]["rows_per_rank"]) == 360
-    assert out["roofline"]["frac"] > 0
+    assert 0 < out["roofline"]["frac"] <= 1.0 and out["roofline"]["bound"] == "mfma"
+    assert out["gather_verified"] is True          # rank 0 re-rendered rows of rank 1: equal to what the gather delivered
 
 
 @pytest.mark.parametrize("build", ["exact", "strict", "fast"])

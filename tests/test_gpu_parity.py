@@ -221,29 +221,32 @@ def test_argument_errors(rt):
 
 
 @pytest.mark.parametrize("build,rng", CHECKED + [("fast", None)])
-@pytest.mark.parametrize("scene,width,spp", [("s3", 1920, 4), ("sf", 1200, 4), ("sf", 3840, 1)])
+@pytest.mark.parametrize("scene,width,spp", [("s3", 1920, 4), ("sf", 1200, 4), ("sf", 3840, 1), ("sf", 3840, 8)])
 def test_full_size_properties(rt, scene, width, spp, build, rng):
     """At the benchmark resolutions the checker is too slow for a full compare; check what does
-    not depend on size: alpha, determinism, part assembly, ray statistics, and a strip of rows
-    against the checker."""
+    not depend on size: alpha, determinism (two full-occupancy launches), part assembly, ray statistics,
+    and a strip of rows against the checker, all with the unit size the library chooses (RT_CHUNK_AUTO)."""
     _, W, H = load_camera_golden(width)
     sph = load_scene(scene)
     rt.set_world(sph)
     cam = rt.camera(W, H)
-    a = rt.render(cam, W, H, spp, 50, build=build, seed=3)
+    auto = rt.CHUNK_AUTO
+    a = rt.render(cam, W, H, spp, 50, build=build, seed=3, chunk_spp=auto)
+    used = int(a["stats"].chunk_spp)
+    assert used == rt.chunk_for(W, H, spp)
     assert (a["rgba"][..., 3] == 255).all()
     assert 2.3 < a["stats"].rays / a["stats"].samples < 3.5
-    again = rt.render(cam, W, H, spp, 50, build=build, seed=3)            # a full-occupancy launch, twice
+    again = rt.render(cam, W, H, spp, 50, build=build, seed=3, chunk_spp=auto)            # a full-occupancy launch, twice
     assert np.array_equal(again["rgba"], a["rgba"]) and again["stats"].rays == a["stats"].rays
     out = np.zeros((H, W, 4), np.uint8)
     for i in range(2):
-        rt.render(cam, W, H, spp, 50, build=build, seed=3, part_index=i, part_count=2, out=out)
+        rt.render(cam, W, H, spp, 50, build=build, seed=3, chunk_spp=auto, part_index=i, part_count=2, out=out)
     assert np.array_equal(out, a["rgba"])
     if rng is None:
         return
     # one row tile of the image against the CPU checker (same counter generator, same samplers)
     tiles = (H + 15) // 16
-    c = rc.render(rc.camera(W, H), sph, W, H, spp, 50, rng=rng, seed=3, tile_rows=16,
+    c = rc.render(rc.camera(W, H), sph, W, H, spp, 50, rng=rng, seed=3, chunk_spp=used, tile_rows=16,
                   part_index=tiles // 2, part_count=tiles)
     rows = rt.part_row_map(H, 16, tiles // 2, tiles)
     assert np.array_equal(a["rgba"][rows], c["rgba"][rows])

@@ -5,9 +5,9 @@ R=$PWD; O=$R/gpurun_out/$1; shift; mkdir -p $O
 for rep in 1 2; do
 for n in "$@"; do
   echo "== $n (round $rep)"
-  RTMI_LIB=$R/tools/librtmi_$n.so RT_CHUNK=-1 timeout -k 10 100 python tools/quick.py 3840 250 2 0 | tail -1 || exit 1
+  RTMI_LIB=$R/tools/librtmi_$n.so RT_CHUNK=-1 timeout -k 10 100 python tools/quick.py 3840 250 2 exact | tail -1 || exit 1
   if [ $rep -eq 1 ]; then
-    RTMI_LIB=$R/tools/librtmi_$n.so RT_CHUNK=-1 timeout -k 10 100 python tools/quick.py 3840 250 1 1 | tail -1 || exit 1
-    RTMI_LIB=$R/tools/librtmi_$n.so RT_CHUNK=-1 timeout -k 10 100 python tools/quick.py 1200 500 2 0 | tail -1 || exit 1
+    RTMI_LIB=$R/tools/librtmi_$n.so RT_CHUNK=-1 timeout -k 10 100 python tools/quick.py 3840 250 1 fast | tail -1 || exit 1
+    RTMI_LIB=$R/tools/librtmi_$n.so RT_CHUNK=-1 timeout -k 10 100 python tools/quick.py 1200 500 2 exact | tail -1 || exit 1
   fi
 done; done

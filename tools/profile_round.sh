@@ -4,6 +4,7 @@
 #   bench_under_rocprof.json   the same command under rocprofv3 --kernel-trace --stats (no CPU leg)
 #   bench_kernel_stats.csv     its per-kernel summary
 #   pmc_workload.txt           the workload the counter passes ran (bench.py matches it before it reports traffic)
+#   pmc_sources.txt            identifies the kernel sources the passes ran on (bench.py matches that too)
 #   pmc_*.csv                  counter passes (each its own run) on bench.py --steps 1 --warmup 0 --no-cpu
 # Everything is written under gpurun_out/<name>/ ; copy what is to be kept into profiles/<name>/.
 set -o pipefail
@@ -20,6 +21,7 @@ import json
 b = json.load(open("$O/bench.json"))
 print("%s, %s build, chunk %d" % (b["config"]["workload"], b["config"]["kernel"], b["config"]["chunk_spp"]))
 PY
+python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.kernel_sources_id())" > $O/pmc_sources.txt
 pass() {   # name, counters...
   local name=$1; shift
   timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d $O/pmc_$name -o p -- python3 $R/bench.py --steps 1 --warmup 0 --no-extras > $O/pmc_$name.json 2> $O/pmc_$name.err || return 1
