@@ -428,6 +428,7 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             const int shared_cost = ((g.n + 63) / 64) * 26 + 60;
             if (is_matrix(scan_variant(g))) tp.coop_max = std::max(2, std::min(16, (150 + g.ntiles * 54 + shared_cost / 2) / shared_cost));
             else tp.coop_max = std::min(16, (g.n_pad / 2 * 9 + 200) / shared_cost);
+            if (const char *cm = getenv("RTMI_COOP")) tp.coop_max = std::max(0, atoi(cm));       // comparison runs
             tp.width = width; tp.height = height; tp.npix = npix;
             tp.tile_rows = tile_rows; tp.part_index = part_index; tp.part_count = part_count;
             tp.rows = nullptr;

@@ -699,14 +699,17 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
         }
     };
     // Per tile: read the NEXT tile's fragments, issue this tile's four MFMAs (the two halves interleaved, so
-    // that no instruction waits for the one before it), compare.  The order matters for correctness, not only
-    // for speed.  A software-pipelined form of this loop, which issued the next tile's LDS reads right AFTER
-    // the MFMAs and let the compiler put them into the registers those MFMAs had just been given (it treats
-    // an operand as read once the instruction is issued), produced wrong accumulators in lanes 48-63 of a few
-    // waves per launch, differently from run to run, at four waves per SIMD on MI355X.  Here the fragment
-    // reads are issued BEFORE the MFMAs, into a buffer of their own (two buffers used in turn), and every
-    // register an MFMA reads stays untouched until its accumulators have been read, which waits for the
-    // instruction to finish; no MFMA is in flight when the scan ends.  This form is deterministic.
+    // that no instruction waits for the one before it), compare.  The fragment reads are issued BEFORE the MFMAs,
+    // into a buffer of their own (two buffers used in turn); every register an MFMA reads stays untouched until
+    // its accumulators have been read (the empty asm in compare() makes the register allocator guarantee it, and
+    // tools/mfma_operand_lint.py checks the generated code), and no MFMA is in flight when the scan ends.
+    // Two other forms of this loop are kept below as compile-time variants because an earlier version of this
+    // comment blamed the wrong thing for what went wrong with them.  Measured on MI355X (profiles/r3_hazard/):
+    // a load that lands in the A/B registers of MFMAs issued just before it does NOT change their result (the
+    // "pipelined" form is bit-identical to this one over 3.3e9 tile products at four waves per SIMD), nor does a
+    // change of EXEC behind an MFMA in flight or right ahead of its issue (tools/mfma_exec_probe.hip); what the
+    // hardware does NOT wait for is a vector instruction's write directly ahead of the MFMA that reads the register
+    // (tools/mfma_valu_raw_probe.hip: one instruction in between suffices; the compiler pads its own code).
     // (the read one tile ahead goes one tile beyond the image at the end of the scan: in LDS that is the geometry
     // and the wave regions behind the image, in global memory a spare tile the host allocates; it is never used)
     auto read_tile = [&](f16x8 (&x)[2], const uint4 *tile) {              // tile: the lane's entry of the tile's first fragment
@@ -714,15 +717,26 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
         for (int s2 = 0; s2 < 2; s2++) x[s2] = __builtin_bit_cast(f16x8, tile[s2 * 64]);
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto do_tile = [&](const f16x8 (&x)[2], int t) {
-        f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[0], as_frag(B[0][0][0], B[0][0][1], B[0][0][2], B[0][0][3]), zero, 0, 0, 0);
-        f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[0], as_frag(B[1][0][0], B[1][0][1], B[1][0][2], B[1][0][3]), zero, 0, 0, 0);
+    auto multiply = [&](const f16x8 (&x)[2], f32x16 &acc0, f32x16 &acc1) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[0], as_frag(B[0][0][0], B[0][0][1], B[0][0][2], B[0][0][3]), zero, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[0], as_frag(B[1][0][0], B[1][0][1], B[1][0][2], B[1][0][3]), zero, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[1], as_frag(B[0][1][0], B[0][1][1], B[0][1][2], B[0][1][3]), acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[1], as_frag(B[1][1][0], B[1][1][1], B[1][1][2], B[1][1][3]), acc1, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+    };
+    // Compares a tile's accumulators with zero and queues what passes.  `x` are the fragments the tile's MFMAs read:
+    // the empty asm takes them as inputs and sits on the data path between the first value computed from the
+    // accumulators and its use, so the register allocator must keep the fragment registers intact until the
+    // accumulators have been read, which the hardware lets happen only when the MFMAs have finished (RT_NO_OPERAND_FENCE
+    // removes it, for the record of what goes wrong without it).
+    auto compare = [&](const f32x16 &acc0, const f32x16 &acc1, const f16x8 (&x)[2], int t) {
         // a half tile adds at most 1024 entries to the at most 63 that wait: kMatListCap
         const RowMaxima rm0 = row_maxima(acc0), rm1 = row_maxima(acc1);
-        if (__ballot(__builtin_fmaxf(rm0.all, rm1.all) >= 0.0f) != 0ULL) {       // two tiles in three hold no candidate at all
+        float any = __builtin_fmaxf(rm0.all, rm1.all);
+#ifndef RT_NO_OPERAND_FENCE
+        asm volatile("" : "+v"(any) : "v"(x[0]), "v"(x[1]));
+#endif
+        if (__ballot(any >= 0.0f) != 0ULL) {       // two tiles in three hold no candidate at all
             queue_passes(acc0, rm0, t * kTileSpheres, ebase0, w.list, cnt RT_DIAG_PASS);
             drain_full_steps();
             queue_passes(acc1, rm1, t * kTileSpheres, ebase1, w.list, cnt RT_DIAG_PASS);
@@ -730,8 +744,75 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    f16x8 a[2], b[2];
     const uint4 *tile = s_aimg + lane;                 // one address register stepped per pair of tiles, constant offsets from it
+#ifdef RT_TILE_LOOP_PIPELINED
+    // The REJECTED form of the loop, kept compilable for the record and for the check of the generated code
+    // (make variant NAME=pipelined DEF="-DRT_TILE_LOOP_PIPELINED -DRT_NO_OPERAND_FENCE"): one fragment buffer, the next
+    // tile's LDS reads issued right after this tile's MFMAs.  The fragments are dead to the compiler once the MFMAs
+    // are issued, so it loads the next tile into the very registers the MFMAs in flight still read.
+    f16x8 x[2];
+    read_tile(x, tile);
+    for (int t = 0; t < p.ntiles; t++, tile += 128) {
+        f32x16 acc0, acc1;
+        multiply(x, acc0, acc1);
+        f16x8 used[2] = {x[0], x[1]};
+        read_tile(x, tile + 128);
+        compare(acc0, acc1, used, t);
+    }
+#elif defined(RT_TILE_LOOP_ROLLING)
+    // Another REJECTED form, kept compilable for the record (make variant NAME=rolling DEF="-DRT_TILE_LOOP_ROLLING
+    // -DRT_NO_OPERAND_FENCE"): the two MFMAs of one ray half are issued before the other half's accumulators are compared
+    // and queued.  In the two builds with IEEE arithmetic its images differ from the kept loop's and from run to run
+    // (long paths at the end of a launch, runs of neighbouring lanes); the fast build's do not.  What was established
+    // about it (profiles/r3_hazard/): the difference does not come from the matrix pipe -- it stays when every product
+    // is followed by a wait that drains the pipe (RT_ROLLING_DRAINED) and goes away when the same pieces run in the
+    // kept loop's order (RT_ROLLING_SERIAL).
+    auto half_product = [&](const f16x8 (&x)[2], int h) {
+        f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[0], as_frag(B[h][0][0], B[h][0][1], B[h][0][2], B[h][0][3]), zero, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[1], as_frag(B[h][1][0], B[h][1][1], B[h][1][2], B[h][1][3]), acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef RT_ROLLING_DRAINED
+        asm volatile("s_sleep 8\n\ts_nop 15" : "+v"(acc));
+#endif
+        return acc;
+    };
+    auto compare_half = [&](const f32x16 &acc, uint32_t ebase, int t) {
+        const RowMaxima rm = row_maxima(acc);
+        if (__ballot(rm.all >= 0.0f) != 0ULL) {
+            queue_passes(acc, rm, t * kTileSpheres, ebase, w.list, cnt RT_DIAG_PASS);
+            drain_full_steps();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    f16x8 a[2], b[2];
+    read_tile(a, tile);
+#ifdef RT_ROLLING_SERIAL
+    for (int t = 0; t < p.ntiles; t++, tile += 128) {
+        read_tile(b, tile + 128);
+        const f32x16 h0 = half_product(a, 0);
+        const f32x16 h1 = half_product(a, 1);
+        compare_half(h0, ebase0, t);
+        compare_half(h1, ebase1, t);
+        a[0] = b[0]; a[1] = b[1];
+    }
+#else
+    f32x16 acc0 = half_product(a, 0);
+    for (int t = 0; t < p.ntiles; t++, tile += 128) {
+        const f32x16 acc1 = half_product(a, 1);
+        read_tile(b, tile + 128);
+        compare_half(acc0, ebase0, t);
+        acc0 = half_product(b, 0);
+        compare_half(acc1, ebase1, t);
+        a[0] = b[0]; a[1] = b[1];
+    }
+#endif
+#else
+    auto do_tile = [&](const f16x8 (&x)[2], int t) {
+        f32x16 acc0, acc1;
+        multiply(x, acc0, acc1);
+        compare(acc0, acc1, x, t);
+    };
+    f16x8 a[2], b[2];
     read_tile(a, tile);
     for (int t = 0; t < p.ntiles; t += 2, tile += 256) {
         read_tile(b, tile + 128);
@@ -741,6 +822,7 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
             do_tile(b, t + 1);
         }
     }
+#endif
 #ifdef RT_DIAG
     dg.scans++;
 #endif
