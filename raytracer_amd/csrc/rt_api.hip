@@ -870,6 +870,14 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
             const rt_sphere &s = spheres[i];
             geom[i] = make_float4(s.center.x, s.center.y, s.center.z, s.radius * s.radius);   // Main.c:650
             matA[i] = make_float4(s.albedo.x, s.albedo.y, s.albedo.z, s.fuzz);
+            if (s.mat_type == RT_MAT_DIELECTRIC) {
+                // reflectance()'s r0 (Main.c:553-554) for a ray entering (ri = 1.0f / index, Main.c:589) and leaving (ri = index)
+                const float ri_in = 1.0f / s.refraction_index, ri_out = s.refraction_index;
+                float r0_in = (1 - ri_in) / (1 + ri_in), r0_out = (1 - ri_out) / (1 + ri_out);
+                r0_in = r0_in * r0_in;
+                r0_out = r0_out * r0_out;
+                matA[i] = make_float4(r0_in, r0_out, 0.0f, s.fuzz);
+            }
             int32_t mt = s.mat_type;
             float mtf;
             memcpy(&mtf, &mt, 4);

@@ -44,11 +44,41 @@ __device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y 
 __device__ __forceinline__ float lensq(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 
 #if RT_STRICT
-__device__ __forceinline__ float rt_sqrt(float x) { return sqrtf(x); }
+// IEEE square root.  The compiler's expansion of sqrtf() is: scale x by 2^32 if it is below 2^-96, v_sqrt_f32 (one ulp),
+// one correction step that tests the two neighbours of the estimate with exact FMA residuals, scale back, and pass
+// zeros and infinities through: 16 instructions.  The scaling only matters for 0 < x < 2^-96 and the pass-through
+// changes nothing (the correction step leaves +-0, +inf, NaN and the NaN of a negative x as v_sqrt_f32 gives them), so
+// for every other x the nine instructions of the core give the same bits.
+__device__ __forceinline__ float sqrt_core(float x)
+{
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float below = __uint_as_float(__float_as_uint(s) - 1U), above = __uint_as_float(__float_as_uint(s) + 1U);
+    const float r_below = __builtin_fmaf(-below, s, x), r_above = __builtin_fmaf(-above, s, x);
+    s = r_below <= 0.0f ? below : s;
+    s = r_above > 0.0f ? above : s;
+    return s;
+}
+// x is known to be zero or at least 2^-96 (or not finite): arguments of the form 1 - y*y with |y| <= 1, (k + 0.5) / 65536 ...
+#ifdef RT_LIBM_SQRT             // comparison builds: the compiler's expansion everywhere
+__device__ __forceinline__ float rt_sqrt_not_tiny(float x) { return sqrtf(x); }
+#else
+__device__ __forceinline__ float rt_sqrt_not_tiny(float x) { return sqrt_core(x); }
+#endif
+// any x: the wave takes the compiler's expansion if one of its lanes holds a tiny positive x
+__device__ __forceinline__ float rt_sqrt(float x)
+{
+#ifdef RT_LIBM_SQRT
+    return sqrtf(x);
+#else
+    if (__builtin_expect(__ballot(__float_as_uint(x) - 1U < 0x0f800000U - 1U) != 0ULL, 0)) return sqrtf(x);     // 0 < x < 2^-96
+    return sqrt_core(x);
+#endif
+}
 __device__ __forceinline__ float rt_div(float a, float b) { return a / b; }
-__device__ __forceinline__ float rt_inv_sqrt(float x) { return 1.0f / sqrtf(x); }
+__device__ __forceinline__ float rt_inv_sqrt(float x) { return 1.0f / rt_sqrt_not_tiny(x); }      // callers pass 0 or x >= 1e-15
 #else
 __device__ __forceinline__ float rt_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float rt_sqrt_not_tiny(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float rt_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 __device__ __forceinline__ float rt_inv_sqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 #endif
@@ -143,11 +173,10 @@ __device__ __forceinline__ V3 random_direction_2d(Rng &r)
     return v3(0.0f, 0.0f, 0.0f);
 }
 
-// reflectance, Main.c:551-556
-__device__ __forceinline__ float reflectance(float cosine, float ri)
+// reflectance, Main.c:551-556; r0 = ((1 - ri) / (1 + ri))^2 comes from the host, which evaluates it with the same two
+// IEEE operations for both sides of every glass sphere (rt_set_world)
+__device__ __forceinline__ float reflectance(float cosine, float r0)
 {
-    float r0 = rt_div(1.0f - ri, 1.0f + ri);
-    r0 = r0 * r0;
     float m = 1.0f - cosine;
     return r0 + (1.0f - r0) * (m * m * m * m * m);
 }
@@ -157,7 +186,7 @@ __device__ __forceinline__ V3 refract(V3 v, V3 n, float e)
 {
     float cos_theta = fminf(dot(scale(v, -1.0f), n), 1.0f);
     V3 perp = scale(add(v, scale(n, cos_theta)), e);
-    V3 par = scale(n, -1.0f * rt_sqrt(fabsf(1.0f - lensq(perp))));
+    V3 par = scale(n, -1.0f * rt_sqrt_not_tiny(fabsf(1.0f - lensq(perp))));      // zero, or at least 2^-24
     return add(perp, par);
 }
 
@@ -209,7 +238,7 @@ __device__ __forceinline__ V3 sphere_direction_direct(Rng &r)
     const uint32_t x = mix32(r.ctr);
     r.ctr += 0x9E3779B9U;
     const float z = fmaf((float)(x >> 16), -1.0f / 32768.0f, 65535.0f / 65536.0f);   // (65535 - 2 k) / 65536, exact
-    const float rad = rt_sqrt(fmaf(-z, z, 1.0f));
+    const float rad = rt_sqrt_not_tiny(fmaf(-z, z, 1.0f));             // at least 1 - (65535 / 65536)^2
     float c, s;
     sincos_turns16(x & 0xffffU, c, s);
     return v3(rad * c, rad * s, z);
@@ -222,7 +251,7 @@ __device__ __forceinline__ void disk_point_direct(Rng &r, float &px, float &py)
     if (MODE == 1) { px = 0.0f; py = 0.0f; return; }
     const uint32_t x = mix32(r.ctr);
     r.ctr += 0x9E3779B9U;
-    const float rad = rt_sqrt(fmaf((float)(x >> 16), 1.0f / 65536.0f, 1.0f / 131072.0f));    // (k + 0.5) / 65536, exact
+    const float rad = rt_sqrt_not_tiny(fmaf((float)(x >> 16), 1.0f / 65536.0f, 1.0f / 131072.0f));    // (k + 0.5) / 65536, exact
     float c, s;
     sincos_turns16(x & 0xffffU, c, s);
     px = rad * c;
@@ -1234,9 +1263,9 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
                     const float ri = front ? mB.w : mB.x;                  // 1.0f / ior, divided on the host (the same IEEE quotient)
                     const V3 ud = normed;
                     const float cos_theta = fminf(dot(scale(ud, -1.0f), n), 1.0f);
-                    const float sin_theta = rt_sqrt(1.0f - cos_theta * cos_theta);
+                    const float sin_theta = rt_sqrt_not_tiny(1.0f - cos_theta * cos_theta);      // zero, or at least 2^-24
                     bool refl = ri * sin_theta > 1.0f;
-                    if (!refl) refl = reflectance(cos_theta, ri) > rng_float<MODE>(L.rng);
+                    if (!refl) refl = reflectance(cos_theta, front ? mA.x : mA.y) > rng_float<MODE>(L.rng);
                     nd = refl ? reflect(ud, n) : refract(ud, n, ri);
                 }
                 if (attenuate) L.thr = mul(L.thr, att);                     // Main.c:738-742
@@ -1273,7 +1302,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
                 const float ri = front ? mB.w : mB.x;                       // 1 / ior from the host
                 const float cos_theta = fminf(cosi, 1.0f);
                 const float sin_theta = rt_sqrt(fmaxf(0.0f, fmaf(-cos_theta, cos_theta, 1.0f)));
-                const bool reflects = (ri * sin_theta > 1.0f) || (reflectance(cos_theta, ri) > u);
+                const bool reflects = (ri * sin_theta > 1.0f) || (reflectance(cos_theta, front ? mA.x : mA.y) > u);
                 const V3 perp = scale(add(L.d, scale(n, cos_theta)), ri);
                 const V3 par = scale(n, -rt_sqrt(fabsf(1.0f - lensq(perp))));
                 const V3 nd_d = reflects ? refl : add(perp, par);
