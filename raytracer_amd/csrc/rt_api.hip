@@ -74,7 +74,7 @@ struct Ctx {
     int nbig = 0;
     int big[kMaxBig] = {0};
     float c_near = 0.0f;
-    DevBuf geom, matA, matB, pairs, aimg, orig;
+    DevBuf geom, matA, matB, pairs, aimg, orig, tbounds;
     int ntiles = 0;              // 32-sphere tiles of the matrix scan's image (0: the scene is too large for it)
     float mat_scale = 1.0f;      // power-of-two scale of the matrix scan's frame
     // scratch
@@ -416,6 +416,7 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             tp.orig = (const int32_t *)g.orig.p;
             tp.pairs = (const float *)g.pairs.p;
             tp.aimg = (const uint4 *)g.aimg.p; tp.ntiles = g.ntiles;
+            tp.tile_bounds = g.ntiles > 0 ? (const float4 *)g.tbounds.p : nullptr;
             tp.mat_scale = g.mat_scale; tp.mat_c_near = g.c_near * g.mat_scale;
             tp.n = g.n; tp.n_pad = g.n_pad;
             tp.nbig = g.nbig; memcpy(tp.big, g.big, sizeof tp.big); tp.c_near = g.c_near;
@@ -462,6 +463,12 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
                 const double per_wave = (double)units / std::max(1.0, waves);
                 const double iters = 3.3 * (double)std::max(1, std::min(chunk, spp));
                 double pool = std::sqrt(192.0 * per_wave / iters);
+                // Short launches end on their longest paths (one sample in two hundred runs all 50 bounces), which a
+                // wave's last pool sits in front of: there a wave should get its work in sixteen pools at least, of
+                // 128 units or more (measured with the exact build, 128 / 256 / 512 units: 1920x1080 x 8 spp 3.08 / 3.04 /
+                // 3.38 ms, 1200x675 x 16 spp 2.60 / 2.60 / 2.81 ms, the 1-spp 1080p frame 1.09 / 1.09 / -; long
+                // launches keep 512: 1200x675 x 500 spp 52.8 / 52.3 / 52.0 ms).
+                pool = std::min(pool, std::max(128.0, per_wave / 16.0));
                 pool = std::min(pool, per_wave / 2.0);
                 tp.pool_units = 64 * (int)std::max(1.0, std::min(8.0, std::floor(pool / 64.0 + 0.5)));
                 if (const char *pu = getenv("RTMI_POOL")) tp.pool_units = std::max(1, atoi(pu));     // comparison runs
@@ -517,6 +524,11 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
                     "rays whose nearest hit differs from the all-spheres exact test: %llu\n",
                     c[5], (double)c[2] / c[5], (double)c[7] / c[5], (double)c[3] / c[5], (double)c[4] / c[5],
                     (double)(c[6] & ((1ULL << 40) - 1)) / c[5], c[6] >> 40, c[1], c[8]);
+#ifndef RT_DIAG_STAMPS
+            if (g.ntiles > 0 && c[5] > 0)
+                fprintf(stderr, "diag: of %d tiles per wave scan, %.2f have a bounding sphere some live ray passes; %.2f have a half (16 spheres) "
+                        "whose bounding sphere some live ray passes\n", g.ntiles, (double)c[9] / c[5], (double)c[10] / c[5]);
+#endif
 #ifdef RT_DIAG_STAMPS
             {
                 const double tot = (double)(c[9] + c[10] + c[11] + c[12] + c[13] + c[14] + c[15]);
@@ -550,7 +562,7 @@ void release_ctx(Ctx &g)
     (void)hipSetDevice(g.device);
     if (g.stream) (void)hipStreamSynchronize(g.stream);
     g.geom.release(); g.matA.release(); g.matB.release(); g.pairs.release();
-    g.aimg.release();
+    g.aimg.release(); g.tbounds.release();
     g.orig.release();
     g.partial.release(); g.running.release(); g.rows.release(); g.counters.release(); g.rgba.release(); g.accum.release(); g.hit.release();
     if (g.ev0) (void)hipEventDestroy(g.ev0);
@@ -966,6 +978,25 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
     // Until every upload to every context has succeeded no context holds a world: a failure in between (out of
     // memory on one device, say) must not leave new scalars next to old buffers, or some contexts on the new
     // world and others on the old one; rt_render then reports RT_ERR_STATE until rt_set_world succeeds.
+    // bounding spheres of the tiles (diagnostic build: how many tiles a coarser test could skip)
+    std::vector<float4> tbounds((size_t)std::max(1, ntiles) * 3, make_float4(0.0f, 0.0f, 0.0f, -1.0f));
+    for (int t = 0; t < ntiles; t++)
+        for (int part = 0; part < 3; part++) {
+            const int i0 = t * kTileSpheres + (part == 2 ? 16 : 0), i1 = std::min(n, t * kTileSpheres + (part == 1 ? 16 : 32));
+            double c[3] = {0, 0, 0};
+            int m = 0;
+            for (int i = i0; i < i1; i++)
+                if (!is_big[i]) { c[0] += spheres[i].center.x; c[1] += spheres[i].center.y; c[2] += spheres[i].center.z; m++; }
+            if (m == 0) continue;
+            for (double &v : c) v /= m;
+            double rad = 0.0;
+            for (int i = i0; i < i1; i++)
+                if (!is_big[i]) {
+                    const double dx = spheres[i].center.x - c[0], dy = spheres[i].center.y - c[1], dz = spheres[i].center.z - c[2];
+                    rad = std::max(rad, std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs((double)spheres[i].radius));
+                }
+            tbounds[(size_t)t * 3 + part] = make_float4((float)c[0], (float)c[1], (float)c[2], (float)(rad * 1.0001));
+        }
     for (int k = 0; k < g_nctx; k++) { g_ctx[k].n_pad = 0; g_ctx[k].n = 0; }
     for (int k = 0; k < g_nctx; k++) {
         Ctx &g = g_ctx[k];
@@ -977,6 +1008,8 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
             HIP_TRY(g.aimg.reserve(aimg.size() * sizeof(uint16_t)));
             HIP_TRY(hipMemcpy(g.aimg.p, aimg.data(), aimg.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         }
+        HIP_TRY(g.tbounds.reserve(tbounds.size() * sizeof(float4)));
+        HIP_TRY(hipMemcpy(g.tbounds.p, tbounds.data(), tbounds.size() * sizeof(float4), hipMemcpyHostToDevice));
         HIP_TRY(g.pairs.reserve(pairs.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(g.pairs.p, pairs.data(), pairs.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(g.orig.reserve(orig.size() * sizeof(int32_t)));

@@ -94,6 +94,8 @@ struct TraceParams {
     const int32_t *orig;                   // [n_pad] device order -> index in the caller's list (hit indices, ties)
     const float *pairs;                    // [n_pad / 2][8]
     const uint4 *aimg;                     // [ntiles][2][64] f16 fragments of the matrix scan, or nullptr
+    const float4 *tile_bounds;             // [ntiles][3] bounding spheres {centre, radius} of a tile's filtered spheres and of its two
+                                           // 16-sphere halves (radius < 0: empty); read by the diagnostic build only
     float mat_scale;                       // power-of-two scale of the matrix scan's frame
     float mat_c_near;                      // max |C| over the filtered spheres, in that frame
     int ntiles;

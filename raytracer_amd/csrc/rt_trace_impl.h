@@ -388,7 +388,7 @@ __device__ __forceinline__ void exact_test(const float4 *s_geom, int i, Probe &q
 // all spheres per ray (lost_hits); RT_DIAG_STAMPS adds shader-clock stamps at the phase boundaries of
 // the main loop (wave-cycles per phase, summed over waves; a stamp drains the scalar-memory queue).
 struct Diag {
-    uint32_t branches, passes, drain_iters, drain_lanes, scans, scan_lanes, shared_rays, lost_hits;
+    uint32_t branches, passes, drain_iters, drain_lanes, scans, scan_lanes, shared_rays, lost_hits, tiles_bound, tiles_halfbound;
     unsigned long long t_handout, t_regen, t_hit, t_drain, t_big, t_shade, t_shared;
 };
 #define RT_DIAG_ARG , Diag &dg
@@ -1027,9 +1027,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
     __syncthreads();
 
     const uint32_t total = (uint32_t)p.total_units;
-#if !RT_STRICT
     const double inv_per_block = 1.0 / (64.0 * (double)p.nchunks), inv_width = 1.0 / (double)p.width;
-#endif
     Lane L;
     L.acc = v3(0.0f, 0.0f, 0.0f);
     L.thr = v3(1.0f, 1.0f, 1.0f);
@@ -1053,7 +1051,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
     pool_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_next);       // wave-uniform by construction
     pool_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_end);
 #ifdef RT_DIAG
-    Diag dg = {0, 0, 0, 0, 0, 0, 0, 0, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
+    Diag dg = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
     const unsigned long long t_wave0 = RT_STAMP();
 #endif
 
@@ -1070,6 +1068,8 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
         unsigned long long want = __ballot(active && need_unit);
         while (want != 0ULL) {
             if (pool_next == pool_end) {
+                // (pools that shrink towards the end of a launch, half an even share of what is left, were measured and
+                // dropped: every refill is a device-wide atomic, and the small launches they were meant for ran 3-4 % slower)
                 unsigned long long b64 = 0;
                 if (lane == 0) b64 = atomicAdd(&p.counters[0], (unsigned long long)pool_units) + static_units;
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64);
@@ -1094,12 +1094,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
                 const uint32_t u = pool_next + rank;
                 const uint32_t per_block = 64U * (uint32_t)p.nchunks;
                 uint32_t blk, rem, rowk;
-#if RT_STRICT
-                blk = u / per_block;
-                rem = u - blk * per_block;
-#else
                 divmod(u, per_block, inv_per_block, blk, rem);
-#endif
                 const uint32_t left = p.npix - blk * 64U;              // pixels of this block: 64, fewer in the last one
                 if (left >= 64U) {
                     L.chunk = (int)(rem >> 6);
@@ -1108,12 +1103,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
                     L.chunk = (int)(rem / left);
                     L.pixc = blk * 64U + (rem - (uint32_t)L.chunk * left);
                 }
-#if RT_STRICT
-                rowk = L.pixc / p.width;
-                L.x = L.pixc - rowk * p.width;
-#else
                 divmod(L.pixc, p.width, inv_width, rowk, L.x);
-#endif
                 L.y = p.rows ? p.rows[rowk] : part_row_at(rowk, p.tile_rows, p.part_index, p.part_count);
                 L.pixhash = mix32((L.x + L.y * p.width) + mix32(p.seed ^ 0x6A09E667U));
                 L.s = L.chunk * p.chunk_spp;
@@ -1180,16 +1170,32 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
             if (is_matrix(VARIANT)) scan_spheres_matrix(p, s_geom, s_aimg, s_orig16, pool, lane, q.dx, q.dy, q.dz, q RT_DIAG_PASS);
             else scan_spheres(p, s_geom, queue, lane, q.dx, q.dy, q.dz, 1.9073486e-6f, q RT_DIAG_PASS);   // 2^-19
         }
-#ifdef RT_DIAG
-        if (__popcll(live) <= p.coop_max) dg.shared_rays += (uint32_t)__popcll(live); else dg.scan_lanes += (uint32_t)__popcll(live);
-#endif
         if (L.zero_dir) q.hit = -1;
+#endif
+#ifdef RT_DIAG
+        { const int nlive = (int)__popcll(__ballot(active)); if (nlive <= p.coop_max) dg.shared_rays += (uint32_t)nlive; else dg.scan_lanes += (uint32_t)nlive; }
 #endif
 #ifdef RT_DIAG
         const unsigned long long ts3 = RT_STAMP();
         if (__popcll(__ballot(active)) <= p.coop_max) dg.t_shared += ts3 - ts2; else dg.t_hit += ts3 - ts2;
 #endif
 #ifdef RT_DIAG_BRUTE
+        if (is_matrix(VARIANT) && p.tile_bounds != nullptr && __popcll(__ballot(active)) > p.coop_max) {
+            // how many tiles would a coarser test let the wave skip?  A tile counts when the line of some live ray
+            // passes its bounding sphere ahead of the origin (or starts inside it)
+            auto passes = [&](const float4 bs) {
+                if (bs.w < 0.0f) return false;
+                const float ocx = bs.x - q.ox, ocy = bs.y - q.oy, ocz = bs.z - q.oz;
+                const float dd = q.dx * q.dx + q.dy * q.dy + q.dz * q.dz;
+                const float h = q.dx * ocx + q.dy * ocy + q.dz * ocz;
+                const float c = ocx * ocx + ocy * ocy + ocz * ocz - bs.w * bs.w;
+                return active && h * h - dd * c >= 0.0f && (h > 0.0f || c < 0.0f);
+            };
+            for (int t = 0; t < p.ntiles; t++) {
+                if (__ballot(passes(p.tile_bounds[3 * t])) != 0ULL) dg.tiles_bound++;
+                if (__ballot(passes(p.tile_bounds[3 * t + 1]) || passes(p.tile_bounds[3 * t + 2])) != 0ULL) dg.tiles_halfbound++;
+            }
+        }
         {
             // Diagnostic build: the exact test over ALL spheres, in index order, must agree with what
             // the filter, the queues and the drain (or the shared-ray search) found for this ray.
@@ -1356,6 +1362,10 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
         atomicAdd(&p.counters[5], (unsigned long long)dg.scans);
         atomicAdd(&p.counters[7], (unsigned long long)dg.passes);
         atomicAdd(&p.counters[6], ((unsigned long long)dg.shared_rays << 40) | (unsigned long long)dg.scan_lanes);
+#ifndef RT_DIAG_STAMPS
+        atomicAdd(&p.counters[9], (unsigned long long)dg.tiles_bound);
+        atomicAdd(&p.counters[10], (unsigned long long)dg.tiles_halfbound);
+#endif
     }
     {
         unsigned long long lost = dg.lost_hits;
