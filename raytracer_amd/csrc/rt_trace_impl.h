@@ -389,6 +389,7 @@ __device__ __forceinline__ void exact_test(const float4 *s_geom, int i, Probe &q
 // the main loop (wave-cycles per phase, summed over waves; a stamp drains the scalar-memory queue).
 struct Diag {
     uint32_t branches, passes, drain_iters, drain_lanes, scans, scan_lanes, shared_rays, lost_hits, tiles_bound, tiles_halfbound;
+    uint32_t scans_by_live[4];      // wave scans with at most 8 / 16 / 32 / 48 live rays
     unsigned long long t_handout, t_regen, t_hit, t_drain, t_big, t_shade, t_shared;
 };
 #define RT_DIAG_ARG , Diag &dg
@@ -637,6 +638,10 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
 {
     const WavePool w = wave_pool(pool_base);
     w.keys[lane] = 0x7f7fffffffffffffULL;                    // max_f32, no sphere
+    // (Measured and dropped: a wave with at most 32 live rays -- a fifth of the scans of a 1-spp frame -- packing them into
+    // the columns of one ray half and running two MFMAs and one compare tree per tile.  Bit-identical, but the sixteen
+    // cross-lane fetches and the second loop body cost registers everywhere: 4K x 250 spp 247 -> 265 ms, the short
+    // launches it was meant for 3.02 -> 3.21 ms and 1.07 -> 1.05 ms.)
 #ifdef RT_DIAG
     const unsigned long long tb0 = RT_STAMP();
 #endif
@@ -1051,7 +1056,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
     pool_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_next);       // wave-uniform by construction
     pool_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_end);
 #ifdef RT_DIAG
-    Diag dg = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
+    Diag dg = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
     const unsigned long long t_wave0 = RT_STAMP();
 #endif
 
@@ -1173,7 +1178,15 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
         if (L.zero_dir) q.hit = -1;
 #endif
 #ifdef RT_DIAG
-        { const int nlive = (int)__popcll(__ballot(active)); if (nlive <= p.coop_max) dg.shared_rays += (uint32_t)nlive; else dg.scan_lanes += (uint32_t)nlive; }
+        {
+            const int nlive = (int)__popcll(__ballot(active));
+            if (nlive <= p.coop_max) dg.shared_rays += (uint32_t)nlive;
+            else {
+                dg.scan_lanes += (uint32_t)nlive;
+                if (nlive <= 8) dg.scans_by_live[0]++; else if (nlive <= 16) dg.scans_by_live[1]++;
+                else if (nlive <= 32) dg.scans_by_live[2]++; else if (nlive <= 48) dg.scans_by_live[3]++;
+            }
+        }
 #endif
 #ifdef RT_DIAG
         const unsigned long long ts3 = RT_STAMP();
@@ -1365,6 +1378,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
 #ifndef RT_DIAG_STAMPS
         atomicAdd(&p.counters[9], (unsigned long long)dg.tiles_bound);
         atomicAdd(&p.counters[10], (unsigned long long)dg.tiles_halfbound);
+        for (int k = 0; k < 4; k++) atomicAdd(&p.counters[11 + k], (unsigned long long)dg.scans_by_live[k]);
 #endif
     }
     {
