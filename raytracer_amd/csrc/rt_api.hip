@@ -35,7 +35,7 @@ static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES]
 
 namespace {
 
-constexpr int kCounters = 20;                    // 64-bit words: [0] next work unit, [1] rays cast, [19] wave scans, the rest diagnostics
+constexpr int kCounters = 24;                    // 64-bit words: [0] next work unit, [1] rays cast, [19] wave scans, the rest diagnostics
 constexpr size_t kScratchCountersBytes = 256;
 constexpr size_t kScratchPartialBytes = (size_t)RT_NOALLOC_SCRATCH_BYTES - kScratchCountersBytes;
 constexpr uint32_t kProgBroken = 0xffffffffu;    // prog_frames of a sequence that must restart at frame 0
@@ -210,15 +210,16 @@ inline float deg_to_rad(float v) { return turns_to_rad(v / 360.f); }
 // of the unit below 8 samples costs about 0.7 % in unit hand-outs, so only images that give a lane of
 // a full MI355X (256 CUs x 2048 lanes) fewer than 128 eight-sample units get shorter ones.  Every unit
 // writes one 16-byte partial sum that the resolve kernel reads back, so the unit grows with the work:
-// the per-chunk sums of the full image stay below 2 GiB (3840x2160 at 1000 spp: 63 samples per unit,
-// 16 chunks, 2.1 GB; with 8 samples per unit it was 16.6 GB of HBM held and written for nothing: a
-// launch with that many units loses nothing to longer ones, measured 230.7 / 229.4 / 229.3 / 228.7 ms
-// at 4 / 8 / 16 / 32 samples per unit on 3840x2160 at 250 spp).
+// the per-chunk sums of the full image stay below 4 GB (3840x2160 at 1000 spp: 34 samples per unit,
+// 30 chunks, 3.98 GB; with 8 samples per unit it was 16.6 GB of HBM held and written for nothing).
+// Measured on that frame, 8 / 16 / 32 / 63 samples per unit: the whole frame 995 / 991 / 987 / 986 ms, and
+// one eighth of it (what a rank of eight renders) at 0.976 / 0.978 / 0.973 / 0.965 of an eighth of the whole:
+// beyond about 32 samples the end of a part's launch starts to show, hence 4 GB and not less.
 int resolve_chunk(int chunk_opt, uint32_t width, uint32_t height, int spp, bool progressive)
 {
     if (chunk_opt != RT_CHUNK_AUTO) return (chunk_opt > 0 && chunk_opt < spp) ? chunk_opt : spp;
     const uint64_t full = (uint64_t)width * (uint64_t)height;
-    const uint64_t max_chunks = std::max<uint64_t>(1, (2ULL << 30) / (std::max<uint64_t>(full, 1) * sizeof(float4)));
+    const uint64_t max_chunks = std::max<uint64_t>(1, 4000000000ULL / (std::max<uint64_t>(full, 1) * sizeof(float4)));
     const uint64_t least = ((uint64_t)spp + max_chunks - 1) / max_chunks;
     const uint64_t lanes = 256ULL * 2048ULL;
     const uint64_t small = std::max<uint64_t>(1, full * (uint64_t)spp / (128 * lanes));
@@ -534,10 +535,10 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
 #endif
 #ifdef RT_DIAG_STAMPS
             {
-                const double tot = (double)(c[9] + c[10] + c[11] + c[12] + c[13] + c[14] + c[15]);
+                const double tot = (double)(c[9] + c[10] + c[11] + c[12] + c[13] + c[14] + c[15] + c[20]);
                 fprintf(stderr, "diag: wave-cycles per phase (share of the main loop): unit hand-out %.2f %%, new sample %.2f %%, "
-                        "pair scan + appends %.2f %%, drain %.2f %%, big spheres %.2f %%, shade %.2f %%, shared-ray search %.2f %%; "
-                        "%.0f cycles per wave scan\n", 100.0 * c[9] / tot, 100.0 * c[10] / tot, 100.0 * c[11] / tot, 100.0 * c[12] / tot,
+                        "ray features %.2f %%, tile loop + appends %.2f %%, drain %.2f %%, big spheres %.2f %%, shade %.2f %%, shared-ray search %.2f %%; "
+                        "%.0f cycles per wave scan\n", 100.0 * c[9] / tot, 100.0 * c[10] / tot, 100.0 * c[20] / tot, 100.0 * c[11] / tot, 100.0 * c[12] / tot,
                         100.0 * c[13] / tot, 100.0 * c[14] / tot, 100.0 * c[15] / tot, tot / (double)c[5]);
                 if (c[18] > 0 && c[17] > 0)
                     fprintf(stderr, "diag: %llu waves lived %.1f %% of the longest wave's %.3f M cycles on average "

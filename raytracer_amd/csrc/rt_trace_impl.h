@@ -390,7 +390,7 @@ __device__ __forceinline__ void exact_test(const float4 *s_geom, int i, Probe &q
 struct Diag {
     uint32_t branches, passes, drain_iters, drain_lanes, scans, scan_lanes, shared_rays, lost_hits, tiles_bound, tiles_halfbound;
     uint32_t scans_by_live[4];      // wave scans with at most 8 / 16 / 32 / 48 live rays
-    unsigned long long t_handout, t_regen, t_hit, t_drain, t_big, t_shade, t_shared;
+    unsigned long long t_handout, t_regen, t_hit, t_drain, t_big, t_shade, t_shared, t_feat;
 };
 #define RT_DIAG_ARG , Diag &dg
 #define RT_DIAG_PASS , dg
@@ -643,7 +643,7 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
     // cross-lane fetches and the second loop body cost registers everywhere: 4K x 250 spp 247 -> 265 ms, the short
     // launches it was meant for 3.02 -> 3.21 ms and 1.07 -> 1.05 ms.)
 #ifdef RT_DIAG
-    const unsigned long long tb0 = RT_STAMP();
+    const unsigned long long tb0 = RT_STAMP(), t_big_before = dg.t_big;
 #endif
     for (int b = 0; b < p.nbig; b++) exact_test(s_geom, p.big[b], q);
 #ifdef RT_DIAG
@@ -723,6 +723,9 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
             const auto sw = __builtin_amdgcn_permlane32_swap(R[8 * s2 + v], R[8 * s2 + 4 + v], false, false);
             B[0][s2][v] = sw[0]; B[1][s2][v] = sw[1];
         }
+#ifdef RT_DIAG
+    dg.t_feat += RT_STAMP() - tb0 - (dg.t_big - t_big_before);        // ray features and their fragments
+#endif
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int cnt = 0;                                             // entries waiting in the wave's list (wave-uniform)
     const uint32_t ebase0 = ((uint32_t)(lane & 31) << 16) | (uint32_t)(lane >> 5), ebase1 = ebase0 + (32U << 16);
@@ -1056,7 +1059,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
     pool_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_next);       // wave-uniform by construction
     pool_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_end);
 #ifdef RT_DIAG
-    Diag dg = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
+    Diag dg = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
     const unsigned long long t_wave0 = RT_STAMP();
     (void)t_wave0;
 #endif
@@ -1391,7 +1394,8 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
     if (__lane_id() == 0) {
         atomicAdd(&p.counters[9], dg.t_handout);
         atomicAdd(&p.counters[10], dg.t_regen);
-        atomicAdd(&p.counters[11], dg.t_hit - dg.t_drain - dg.t_big);      // the pair loop with its appends
+        atomicAdd(&p.counters[11], dg.t_hit - dg.t_drain - dg.t_big - dg.t_feat);      // the tile (pair) loop with its appends
+        atomicAdd(&p.counters[20], dg.t_feat);
         atomicAdd(&p.counters[12], dg.t_drain);
         atomicAdd(&p.counters[13], dg.t_big);
         atomicAdd(&p.counters[14], dg.t_shade);
