@@ -535,10 +535,10 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
 #endif
 #ifdef RT_DIAG_STAMPS
             {
-                const double tot = (double)(c[9] + c[10] + c[11] + c[12] + c[13] + c[14] + c[15] + c[20]);
+                const double tot = (double)(c[9] + c[10] + c[11] + c[12] + c[13] + c[14] + c[15] + c[20] + c[21]);
                 fprintf(stderr, "diag: wave-cycles per phase (share of the main loop): unit hand-out %.2f %%, new sample %.2f %%, "
-                        "ray features %.2f %%, tile loop + appends %.2f %%, drain %.2f %%, big spheres %.2f %%, shade %.2f %%, shared-ray search %.2f %%; "
-                        "%.0f cycles per wave scan\n", 100.0 * c[9] / tot, 100.0 * c[10] / tot, 100.0 * c[20] / tot, 100.0 * c[11] / tot, 100.0 * c[12] / tot,
+                        "ray features %.2f %%, tile loop (products, compares) %.2f %%, appends %.2f %%, drain %.2f %%, big spheres %.2f %%, shade %.2f %%, shared-ray search %.2f %%; "
+                        "%.0f cycles per wave scan\n", 100.0 * c[9] / tot, 100.0 * c[10] / tot, 100.0 * c[20] / tot, 100.0 * c[11] / tot, 100.0 * c[21] / tot, 100.0 * c[12] / tot,
                         100.0 * c[13] / tot, 100.0 * c[14] / tot, 100.0 * c[15] / tot, tot / (double)c[5]);
                 if (c[18] > 0 && c[17] > 0)
                     fprintf(stderr, "diag: %llu waves lived %.1f %% of the longest wave's %.3f M cycles on average "

@@ -390,7 +390,7 @@ __device__ __forceinline__ void exact_test(const float4 *s_geom, int i, Probe &q
 struct Diag {
     uint32_t branches, passes, drain_iters, drain_lanes, scans, scan_lanes, shared_rays, lost_hits, tiles_bound, tiles_halfbound;
     uint32_t scans_by_live[4];      // wave scans with at most 8 / 16 / 32 / 48 live rays
-    unsigned long long t_handout, t_regen, t_hit, t_drain, t_big, t_shade, t_shared, t_feat;
+    unsigned long long t_handout, t_regen, t_hit, t_drain, t_big, t_shade, t_shared, t_feat, t_append;
 };
 #define RT_DIAG_ARG , Diag &dg
 #define RT_DIAG_PASS , dg
@@ -648,6 +648,9 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
     for (int b = 0; b < p.nbig; b++) exact_test(s_geom, p.big[b], q);
 #ifdef RT_DIAG
     dg.t_big += RT_STAMP() - tb0;
+#ifdef RT_DIAG_STAMPS
+    asm volatile("" : "+v"(ux), "+v"(uy), "+v"(uz));          // the feature arithmetic stays between its two stamps
+#endif
 #endif
     // ray features in the frame scaled by p.mat_scale (a power of two)
     const float ox = q.ox * p.mat_scale, oy = q.oy * p.mat_scale, oz = q.oz * p.mat_scale;
@@ -724,6 +727,10 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
             B[0][s2][v] = sw[0]; B[1][s2][v] = sw[1];
         }
 #ifdef RT_DIAG
+#ifdef RT_DIAG_STAMPS
+#pragma unroll
+    for (int k = 0; k < 16; k++) asm volatile("" : "+v"(B[k >> 3][(k >> 2) & 1][k & 3]));
+#endif
     dg.t_feat += RT_STAMP() - tb0 - (dg.t_big - t_big_before);        // ray features and their fragments
 #endif
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -774,10 +781,16 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
         asm volatile("" : "+v"(any) : "v"(x[0]), "v"(x[1]));
 #endif
         if (__ballot(any >= 0.0f) != 0ULL) {       // two tiles in three hold no candidate at all
+#ifdef RT_DIAG
+            const unsigned long long ta0 = RT_STAMP(), drain_before = dg.t_drain;
+#endif
             queue_passes(acc0, rm0, t * kTileSpheres, ebase0, w.list, cnt RT_DIAG_PASS);
             drain_full_steps();
             queue_passes(acc1, rm1, t * kTileSpheres, ebase1, w.list, cnt RT_DIAG_PASS);
             drain_full_steps();
+#ifdef RT_DIAG
+            dg.t_append += RT_STAMP() - ta0 - (dg.t_drain - drain_before);
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -1059,7 +1072,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
     pool_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_next);       // wave-uniform by construction
     pool_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_end);
 #ifdef RT_DIAG
-    Diag dg = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
+    Diag dg = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
     const unsigned long long t_wave0 = RT_STAMP();
     (void)t_wave0;
 #endif
@@ -1394,8 +1407,9 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
     if (__lane_id() == 0) {
         atomicAdd(&p.counters[9], dg.t_handout);
         atomicAdd(&p.counters[10], dg.t_regen);
-        atomicAdd(&p.counters[11], dg.t_hit - dg.t_drain - dg.t_big - dg.t_feat);      // the tile (pair) loop with its appends
+        atomicAdd(&p.counters[11], dg.t_hit - dg.t_drain - dg.t_big - dg.t_feat - dg.t_append);      // the tile (pair) loop: products and compares
         atomicAdd(&p.counters[20], dg.t_feat);
+        atomicAdd(&p.counters[21], dg.t_append);
         atomicAdd(&p.counters[12], dg.t_drain);
         atomicAdd(&p.counters[13], dg.t_big);
         atomicAdd(&p.counters[14], dg.t_shade);
