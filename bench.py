@@ -221,6 +221,9 @@ def main():
                     help="gloo stages the gather through host memory (rehearsal only)")
     ap.add_argument("--shared-gpu", action="store_true",
                     help="rehearsal of the N > 1 path on a one-GPU box: every rank uses device 0 (needs --backend gloo)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1: run the process-group calls of the N > 1 path (init, all_reduce, gather, barrier) with one rank, "
+                         "so that a one-GPU box executes the RCCL branch")
     ap.add_argument("--mock", action="store_true", help="no GPU, no kernel: checks the N > 1 plumbing and the JSON shape (needs --backend gloo)")
     ap.add_argument("--n1-value", type=float, default=0.0, help="the N = 1 value of the same workload: adds efficiency_vs_n1")
     ap.add_argument("--cpu-width", type=int, default=3840)
@@ -256,8 +259,10 @@ def main():
             local = 0
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -284,7 +289,8 @@ def main():
         part.weights = [float(w) for w in weights]
         part.rows = weighted_row_maps(H, args.tile_rows, part.weights)
         # compact owned rows -> full image on rank 0
-        part.rg = RowGather(part.rows, W, 4, torch.uint8, dev, rank, world, via_host=(args.backend == "gloo"))
+        part.rg = RowGather(part.rows, W, 4, torch.uint8, dev, rank, world, via_host=(args.backend == "gloo"),
+                            always_collective=dist_on)
         if args.mock:
             for b in part.rg._send:
                 rt.buffers[b.data_ptr()] = b
@@ -294,7 +300,7 @@ def main():
     part.rg.connect()                                              # peer connections exist before anything is timed
 
     def sync():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         if on_gpu:
             torch.cuda.synchronize()
@@ -313,7 +319,7 @@ def main():
 
     for i in range(args.warmup):
         st = step(args.build)
-        if world > 1 and not args.no_rebalance and i < max(1, args.warmup - 1):
+        if dist_on and not args.no_rebalance and i < max(1, args.warmup - 1):
             # MI355X devices hold different clocks on this compute-bound kernel (10 % apart is
             # common): deal the row tiles in proportion to the speed each rank just showed, so
             # that all ranks finish together (again after every warm-up step but the last, which
@@ -334,7 +340,7 @@ def main():
     kernel_ms = float(np.mean([s.kernel_ms for s in stats]))                 # HIP events on the library's stream
     per_rank_kernel_ms = [kernel_ms]
     per_rank_gather_ms = [float(np.mean(gather_ms))]
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -354,7 +360,7 @@ def main():
         # own itself (the image does not depend on who renders a row) and compares them with what the gather
         # delivered, byte for byte; not timed.
         gather_verified = None
-        if rank == 0 and not args.mock:
+        if rank == 0 and not args.mock and world > 1:
             foreign = np.concatenate([np.asarray(part.rows[r]) for r in range(1, world)])
             probe = np.unique(foreign[np.linspace(0, len(foreign) - 1, 16).astype(np.int64)]).astype(np.uint32)
             mine = torch.zeros((len(probe), W, 4), dtype=torch.uint8, device=dev)
@@ -457,7 +463,7 @@ def main():
         }
         if args.mock:
             out["mock"] = True
-        if world > 1:
+        if dist_on:
             out["backend"] = dist.get_backend()
             out["dist_world"] = dist.get_world_size()
             out["kernel_ms_per_rank"] = per_rank_kernel_ms
@@ -512,7 +518,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     rt.shutdown()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -527,8 +527,9 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
                     (double)(c[6] & ((1ULL << 40) - 1)) / c[5], c[6] >> 40, c[1], c[8]);
 #ifndef RT_DIAG_STAMPS
             if (g.ntiles > 0 && c[5] > 0)
-                fprintf(stderr, "diag: of %d tiles per wave scan, %.2f have a bounding sphere some live ray passes; %.2f have a half (16 spheres) "
-                        "whose bounding sphere some live ray passes\n", g.ntiles, (double)c[9] / c[5], (double)c[10] / c[5]);
+                fprintf(stderr, "diag: of %d tiles per wave scan, %.2f have a bounding sphere some live ray passes; of %d (tile, half of the wave's rays) "
+                        "pairs %.2f; of %d (16-sphere half tile, half of the rays) pairs %.2f\n", g.ntiles, (double)c[9] / c[5], 2 * g.ntiles,
+                        (double)c[10] / c[5], 4 * g.ntiles, (double)c[15] / c[5]);
             if (c[5] > 0)
                 fprintf(stderr, "diag: share of the wave scans with 5-8 / 9-16 / 17-32 / 33-48 live rays: %.1f / %.1f / %.1f / %.1f %%\n",
                         100.0 * c[11] / c[5], 100.0 * c[12] / c[5], 100.0 * c[13] / c[5], 100.0 * c[14] / c[5]);

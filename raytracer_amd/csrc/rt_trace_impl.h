@@ -388,7 +388,7 @@ __device__ __forceinline__ void exact_test(const float4 *s_geom, int i, Probe &q
 // all spheres per ray (lost_hits); RT_DIAG_STAMPS adds shader-clock stamps at the phase boundaries of
 // the main loop (wave-cycles per phase, summed over waves; a stamp drains the scalar-memory queue).
 struct Diag {
-    uint32_t branches, passes, drain_iters, drain_lanes, scans, scan_lanes, shared_rays, lost_hits, tiles_bound, tiles_halfbound;
+    uint32_t branches, passes, drain_iters, drain_lanes, scans, scan_lanes, shared_rays, lost_hits, tiles_bound, tiles_halfbound, quads_bound;
     uint32_t scans_by_live[4];      // wave scans with at most 8 / 16 / 32 / 48 live rays
     unsigned long long t_handout, t_regen, t_hit, t_drain, t_big, t_shade, t_shared, t_feat, t_append;
 };
@@ -402,6 +402,13 @@ struct Diag {
 #else
 #define RT_DIAG_ARG
 #define RT_DIAG_PASS
+#endif
+
+// make isa ISADEF=-DRT_ISA_MARKS: comment lines in the generated assembly at the phase boundaries (tools/isa_cost.py)
+#ifdef RT_ISA_MARKS
+#define RT_MARK(name) asm volatile("; MARK " name)
+#else
+#define RT_MARK(name)
 #endif
 
 constexpr int kQueueSlots = RT_STRICT ? kQueueSlotsStrict : kQueueSlotsFast;   // per lane
@@ -542,6 +549,7 @@ __device__ __forceinline__ void drain_pooled(const float4 *s_geom, const uint16_
     const unsigned long long t0 = RT_STAMP();
     dg.drain_iters++; dg.drain_lanes += (uint32_t)count;
 #endif
+    RT_MARK("drain_pooled");
     const bool mine = lane < count;
     const uint32_t e = w.list[first + (mine ? lane : 0)];
     const uint32_t ray = e >> 16, sph = e & 0xffffU;
@@ -589,6 +597,7 @@ __device__ __forceinline__ RowMaxima row_maxima(const f32x16 &acc)
 
 __device__ __forceinline__ void queue_passes(const f32x16 &acc, const RowMaxima &rm, int first, uint32_t ebase, uint32_t *list, int &cnt RT_DIAG_ARG)
 {
+    RT_MARK("queue_passes");
     if (__ballot(rm.all >= 0.0f) != 0ULL) {
 #ifdef RT_DIAG
         dg.branches++;
@@ -636,6 +645,7 @@ __device__ __forceinline__ void queue_passes(const f32x16 &acc, const RowMaxima 
 __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const float4 *s_geom, const uint4 *s_aimg, const uint16_t *s_orig16,
                                                     char *pool_base, int lane, float ux, float uy, float uz, Probe &q RT_DIAG_ARG)
 {
+    RT_MARK("scan_begin_big");
     const WavePool w = wave_pool(pool_base);
     w.keys[lane] = 0x7f7fffffffffffffULL;                    // max_f32, no sphere
     // (Measured and dropped: a wave with at most 32 live rays -- a fifth of the scans of a 1-spp frame -- packing them into
@@ -652,6 +662,7 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
     asm volatile("" : "+v"(ux), "+v"(uy), "+v"(uz));          // the feature arithmetic stays between its two stamps
 #endif
 #endif
+    RT_MARK("features");
     // ray features in the frame scaled by p.mat_scale (a power of two)
     const float ox = q.ox * p.mat_scale, oy = q.oy * p.mat_scale, oz = q.oz * p.mat_scale;
     const float oo = fmaf(oz, oz, fmaf(oy, oy, ox * ox));
@@ -733,6 +744,7 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
 #endif
     dg.t_feat += RT_STAMP() - tb0 - (dg.t_big - t_big_before);        // ray features and their fragments
 #endif
+    RT_MARK("tile_loop_setup");
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int cnt = 0;                                             // entries waiting in the wave's list (wave-uniform)
     const uint32_t ebase0 = ((uint32_t)(lane & 31) << 16) | (uint32_t)(lane >> 5), ebase1 = ebase0 + (32U << 16);
@@ -740,6 +752,9 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
         while (cnt >= 64) {
             cnt -= 64;
             drain_pooled(s_geom, s_orig16, p.orig, w, cnt, 64, lane, q RT_DIAG_PASS);
+#ifdef RT_X_DOUBLE_DRAIN       // marginal-cost experiment: every dense step of exact tests runs twice (lowering a key twice changes nothing)
+            drain_pooled(s_geom, s_orig16, p.orig, w, cnt, 64, lane, q RT_DIAG_PASS);
+#endif
         }
     };
     // Per tile: read the NEXT tile's fragments, issue this tile's four MFMAs (the two halves interleaved, so
@@ -784,8 +799,14 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
 #ifdef RT_DIAG
             const unsigned long long ta0 = RT_STAMP(), drain_before = dg.t_drain;
 #endif
+#ifdef RT_X_DOUBLE_APPEND      // marginal-cost experiment (tools/marginal_costs.sh): the appends run twice, the same entries to the same slots
+            { int again = cnt; queue_passes(acc0, rm0, t * kTileSpheres, ebase0, w.list, again RT_DIAG_PASS); }
+#endif
             queue_passes(acc0, rm0, t * kTileSpheres, ebase0, w.list, cnt RT_DIAG_PASS);
             drain_full_steps();
+#ifdef RT_X_DOUBLE_APPEND
+            { int again = cnt; queue_passes(acc1, rm1, t * kTileSpheres, ebase1, w.list, again RT_DIAG_PASS); }
+#endif
             queue_passes(acc1, rm1, t * kTileSpheres, ebase1, w.list, cnt RT_DIAG_PASS);
             drain_full_steps();
 #ifdef RT_DIAG
@@ -859,7 +880,23 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
 #else
     auto do_tile = [&](const f16x8 (&x)[2], int t) {
         f32x16 acc0, acc1;
+#ifdef RT_X_DOUBLE_TILE        // marginal-cost experiment: every tile's products (1), maxima (2) or both (3) are computed twice
         multiply(x, acc0, acc1);
+        asm volatile("" : "+v"(acc0), "+v"(acc1) : "v"(x[0]), "v"(x[1]));
+#if RT_X_DOUBLE_TILE != 1
+        {
+            const RowMaxima r0 = row_maxima(acc0), r1 = row_maxima(acc1);
+            float sink = __builtin_fmaxf(r0.all, r1.all);
+            asm volatile("" : "+v"(sink));
+            if (__ballot(sink == 12345.0f) != 0ULL) asm volatile("s_nop 0");
+            asm volatile("" : "+v"(acc0), "+v"(acc1));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+#endif
+#if !defined(RT_X_DOUBLE_TILE) || RT_X_DOUBLE_TILE != 2
+        multiply(x, acc0, acc1);
+#endif
         compare(acc0, acc1, x, t);
     };
     f16x8 a[2], b[2];
@@ -876,7 +913,11 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
 #ifdef RT_DIAG
     dg.scans++;
 #endif
+    RT_MARK("scan_tail");
     if (cnt > 0) drain_pooled(s_geom, s_orig16, p.orig, w, 0, cnt, lane, q RT_DIAG_PASS);
+#ifdef RT_X_DOUBLE_DRAIN
+    if (cnt > 0) drain_pooled(s_geom, s_orig16, p.orig, w, 0, cnt, lane, q RT_DIAG_PASS);
+#endif
     // the lane's own ray: what the pooled tests found against what the big spheres gave
     const unsigned long long key = w.keys[lane];
     const uint32_t low = (uint32_t)key;
@@ -1072,7 +1113,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
     pool_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_next);       // wave-uniform by construction
     pool_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_end);
 #ifdef RT_DIAG
-    Diag dg = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
+    Diag dg = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
     const unsigned long long t_wave0 = RT_STAMP();
     (void)t_wave0;
 #endif
@@ -1087,6 +1128,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
 #ifdef RT_DIAG
         const unsigned long long ts0 = RT_STAMP();
 #endif
+        RT_MARK("handout");
         unsigned long long want = __ballot(active && need_unit);
         while (want != 0ULL) {
             if (pool_next == pool_end) {
@@ -1143,6 +1185,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
         dg.t_handout += ts1 - ts0;
 #endif
 
+        RT_MARK("new_sample");
         // ---- start a new sample where the previous path ended ------------------------
         if (active && need_sample) {
             L.rng.ctr = mix32(L.pixhash ^ ((p.sample_base + (uint32_t)L.s) * 0x9E3779B9U));
@@ -1155,6 +1198,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
         const unsigned long long ts2 = RT_STAMP();
         dg.t_regen += ts2 - ts1;
 #endif
+        RT_MARK("hit");
         // ---- hit(): nearest sphere along the ray, Main.c:688-713 -----------------------
         Probe q;
         q.ox = L.o.x; q.oy = L.o.y; q.oz = L.o.z;
@@ -1222,8 +1266,13 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
                 return active && h * h - dd * c >= 0.0f && (h > 0.0f || c < 0.0f);
             };
             for (int t = 0; t < p.ntiles; t++) {
-                if (__ballot(passes(p.tile_bounds[3 * t])) != 0ULL) dg.tiles_bound++;
-                if (__ballot(passes(p.tile_bounds[3 * t + 1]) || passes(p.tile_bounds[3 * t + 2])) != 0ULL) dg.tiles_halfbound++;
+                // ... and per half of the wave's rays (the 32 columns of one matrix product): (tile, ray half) pairs of 2 per tile,
+                // (16-sphere half tile, ray half) pairs of 4 per tile
+                const unsigned long long m = __ballot(passes(p.tile_bounds[3 * t]));
+                if (m != 0ULL) dg.tiles_bound++;
+                dg.tiles_halfbound += ((uint32_t)m != 0U) + ((uint32_t)(m >> 32) != 0U);
+                const unsigned long long m1 = __ballot(passes(p.tile_bounds[3 * t + 1])), m2 = __ballot(passes(p.tile_bounds[3 * t + 2]));
+                dg.quads_bound += ((uint32_t)m1 != 0U) + ((uint32_t)(m1 >> 32) != 0U) + ((uint32_t)m2 != 0U) + ((uint32_t)(m2 >> 32) != 0U);
             }
         }
         {
@@ -1249,6 +1298,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
         const float closest = q.closest;
         const int hit = q.hit;
 
+        RT_MARK("shade");
         // ---- shade: ray_color's loop body, Main.c:730-759 ------------------------------
         if (active) {
             rays++;
@@ -1375,8 +1425,26 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
 #ifdef RT_DIAG
         dg.t_shade += RT_STAMP() - ts3;
 #endif
+#ifdef RT_X_PAD_VALU           // marginal-cost experiment: RT_X_PAD_VALU more vector instructions per iteration (RT_X_PAD_KIND 0: one dependent
+                               // chain of v_fma_f32, 1: four independent chains, 2: v_max3_f32, four chains)
+        {
+            float d0 = L.o.x, d1 = L.o.y, d2 = L.o.z, d3 = L.tmin;
+#pragma unroll
+            for (int k = 0; k < RT_X_PAD_VALU / 4; k++) {
+#if RT_X_PAD_KIND == 0
+                asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %0, %0, %0, %0" : "+v"(d0));
+#elif RT_X_PAD_KIND == 1
+                asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+#else
+                asm volatile("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %1, %1, %2, %3\n\tv_max3_f32 %2, %2, %3, %0\n\tv_max3_f32 %3, %3, %0, %1" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+#endif
+            }
+            asm volatile("" :: "v"(d0), "v"(d1), "v"(d2), "v"(d3));
+        }
+#endif
     }
 
+    RT_MARK("epilogue");
     // ---- statistics: rays cast, sphere scans run by the waves ------------------------------
     unsigned long long r64 = rays;
     for (int off = 32; off > 0; off >>= 1) r64 += __shfl_down(r64, off);
@@ -1395,6 +1463,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
 #ifndef RT_DIAG_STAMPS
         atomicAdd(&p.counters[9], (unsigned long long)dg.tiles_bound);
         atomicAdd(&p.counters[10], (unsigned long long)dg.tiles_halfbound);
+        atomicAdd(&p.counters[15], (unsigned long long)dg.quads_bound);
         for (int k = 0; k < 4; k++) atomicAdd(&p.counters[11 + k], (unsigned long long)dg.scans_by_live[k]);
 #endif
     }

@@ -33,11 +33,14 @@ def weighted_row_maps(height, tile_rows, weights):
 
 
 class RowGather:
-    def __init__(self, row_maps, width, channels, dtype, device, rank, world, via_host=False):
+    def __init__(self, row_maps, width, channels, dtype, device, rank, world, via_host=False, always_collective=False):
         """row_maps[i] = image rows owned by rank i (ascending), e.g. raytracer_amd.part_row_map.
         via_host: the process group cannot move device tensors (gloo with GPU buffers, used to
-        rehearse the N > 1 path on a one-GPU box): stage the rows through host memory."""
+        rehearse the N > 1 path on a one-GPU box): stage the rows through host memory.
+        always_collective: call the process group's gather even when it has one rank (a one-GPU box can then
+        run the RCCL calls of the N > 1 path: RCCL refuses two ranks on one device, not one)."""
         self.rank, self.world = rank, world
+        self.collective = world > 1 or bool(always_collective)
         self.via_host = bool(via_host) and torch.device(device).type != "cpu"
         self.counts = [len(r) for r in row_maps]
         self.max_rows = max(self.counts) if self.counts else 0
@@ -51,9 +54,9 @@ class RowGather:
         self._done = [None, None]
         self.full = torch.zeros((height, width, channels), dtype=dtype, device=device) if rank == 0 else None
         self.recv = ([torch.zeros_like(self._send[0]) for _ in range(world)]
-                     if (rank == 0 and world > 1) else None)
+                     if (rank == 0 and self.collective) else None)
         self.idx = [torch.as_tensor(r, dtype=torch.int64, device=device) for r in row_maps] if rank == 0 else None
-        if self.via_host and world > 1:
+        if self.via_host and self.collective:
             self.host_mine = torch.zeros(self._send[0].shape, dtype=dtype)
             self.host_recv = [torch.zeros_like(self.host_mine) for _ in range(world)] if rank == 0 else None
 
@@ -84,7 +87,7 @@ class RowGather:
         return full
 
     def _gather(self, mine):
-        if self.world > 1:
+        if self.collective:
             if self.via_host:
                 self.host_mine.copy_(mine)
                 dist.gather(self.host_mine, self.host_recv, dst=0)

@@ -55,6 +55,20 @@ def test_bench_two_ranks_one_gpu(tmp_path):
     assert out["gather_verified"] is True          # rank 0 re-rendered rows of rank 1: equal to what the gather delivered
 
 
+def test_bench_rccl_calls_with_one_rank():
+    """The RCCL branch of bench.py's N > 1 path on the one GPU of the test box: a process group of ONE rank on the
+    "nccl" backend (RCCL refuses two ranks on a device, not one) runs the same calls as the 8-GPU job:
+    init_process_group with a device id, all_reduce and gather on device tensors, barrier."""
+    import json
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "2", "--width", "640",
+           "--spp", "40", "--chunk", "10", "--force-dist", "--no-extras"]
+    res = subprocess.run(cmd, check=True, timeout=240, cwd=ROOT, stdout=subprocess.PIPE, env=env)
+    out = json.loads([l for l in res.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert out["backend"] == "nccl" and out["dist_world"] == 1 and out["value"] > 0
+    assert out["rows_per_rank"] == [360] and out["gather_verified"] is None        # no other rank's rows to re-render
+
+
 @pytest.mark.parametrize("build", ["exact", "strict", "fast"])
 def test_several_contexts_in_one_process(rt, build):
     """rt_init_devices: three contexts (sharing the one device of the test box) split a frame by
