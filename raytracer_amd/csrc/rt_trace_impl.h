@@ -881,21 +881,43 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
     auto do_tile = [&](const f16x8 (&x)[2], int t) {
         f32x16 acc0, acc1;
 #ifdef RT_X_DOUBLE_TILE        // marginal-cost experiment: every tile's products (1), maxima (2) or both (3) are computed twice
-        multiply(x, acc0, acc1);
-        asm volatile("" : "+v"(acc0), "+v"(acc1) : "v"(x[0]), "v"(x[1]));
-#if RT_X_DOUBLE_TILE != 1
         {
-            const RowMaxima r0 = row_maxima(acc0), r1 = row_maxima(acc1);
+            // the extra products permute B's lane groups (blgp), so that they are not the same expression as the real ones; the extra
+            // maxima are taken of them.  Inputs of an empty asm keep them alive without copies.
+            f32x16 g0, g1;
+#if RT_X_DOUBLE_TILE != 2
+            g0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[0], as_frag(B[0][0][0], B[0][0][1], B[0][0][2], B[0][0][3]), zero, 0, 0, 1);
+            g1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[0], as_frag(B[1][0][0], B[1][0][1], B[1][0][2], B[1][0][3]), zero, 0, 0, 1);
+            g0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[1], as_frag(B[0][1][0], B[0][1][1], B[0][1][2], B[0][1][3]), g0, 0, 0, 1);
+            g1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[1], as_frag(B[1][1][0], B[1][1][1], B[1][1][2], B[1][1][3]), g1, 0, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#if RT_X_DOUBLE_TILE == 1
+            asm volatile("" :: "v"(g0), "v"(g1));
+#elif RT_X_DOUBLE_TILE == 3
+            const RowMaxima r0 = row_maxima(g0), r1 = row_maxima(g1);
             float sink = __builtin_fmaxf(r0.all, r1.all);
             asm volatile("" : "+v"(sink));
             if (__ballot(sink == 12345.0f) != 0ULL) asm volatile("s_nop 0");
-            asm volatile("" : "+v"(acc0), "+v"(acc1));
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
 #endif
-#endif
-#if !defined(RT_X_DOUBLE_TILE) || RT_X_DOUBLE_TILE != 2
         multiply(x, acc0, acc1);
+#if defined(RT_X_DOUBLE_TILE) && RT_X_DOUBLE_TILE == 2
+        {
+            // the same number of maxima over the real accumulators, grouped differently (not the expressions compare() evaluates)
+            auto shifted = [](const f32x16 &a) {
+                float m[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) m[k] = __builtin_fmaxf(__builtin_fmaxf(a[3 * k + 1], a[3 * k + 2]), a[3 * k + 3]);
+                return __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(m[0], m[1]), a[0]), __builtin_fmaxf(__builtin_fmaxf(m[2], m[3]), m[4]));
+            };
+            float sink = __builtin_fmaxf(shifted(acc0), shifted(acc1));
+            asm volatile("" : "+v"(sink));
+            if (__ballot(sink == 12345.0f) != 0ULL) asm volatile("s_nop 0");
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #endif
         compare(acc0, acc1, x, t);
     };
