@@ -904,6 +904,17 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
         }
 #endif
         multiply(x, acc0, acc1);
+#ifdef RT_X_SHADOW_PAD         // marginal-cost experiment: RT_X_SHADOW_PAD independent v_fma_f32 of the same wave behind its four products, i.e. in
+                               // the time it would otherwise wait for them
+        {
+            float d0 = ux, d1 = uy, d2 = uz, d3 = q.tmin;
+#pragma unroll
+            for (int k = 0; k < RT_X_SHADOW_PAD / 4; k++)
+                asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+            asm volatile("" :: "v"(d0), "v"(d1), "v"(d2), "v"(d3));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
 #if defined(RT_X_DOUBLE_TILE) && RT_X_DOUBLE_TILE == 2
         {
             // the same number of maxima over the real accumulators, grouped differently (not the expressions compare() evaluates)
