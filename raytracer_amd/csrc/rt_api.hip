@@ -74,6 +74,7 @@ struct Ctx {
     int nbig = 0;
     int big[kMaxBig] = {0};
     float c_near = 0.0f;
+    int core_div_ok = 0;         // every sphere within 2^24 of the origin (TraceParams::core_div_ok)
     DevBuf geom, matA, matB, pairs, aimg, orig, tbounds;
     int ntiles = 0;              // 32-sphere tiles of the matrix scan's image (0: the scene is too large for it)
     float mat_scale = 1.0f;      // power-of-two scale of the matrix scan's frame
@@ -420,7 +421,7 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             tp.tile_bounds = g.ntiles > 0 ? (const float4 *)g.tbounds.p : nullptr;
             tp.mat_scale = g.mat_scale; tp.mat_c_near = g.c_near * g.mat_scale;
             tp.n = g.n; tp.n_pad = g.n_pad;
-            tp.nbig = g.nbig; memcpy(tp.big, g.big, sizeof tp.big); tp.c_near = g.c_near;
+            tp.nbig = g.nbig; memcpy(tp.big, g.big, sizeof tp.big); tp.c_near = g.c_near; tp.core_div_ok = g.core_div_ok;
             // one ray over all spheres costs about 9 vector instructions per sphere pair in the packed-FP32
             // scan (for all 64 lanes at once) and about 26 per 64 spheres plus a 6-step reduction when the
             // lanes share one ray: the shared form wins while few rays are left in the wave.  The matrix scan
@@ -1028,6 +1029,7 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
         g.nbig = nbig;
         memcpy(g.big, big, sizeof big);
         g.c_near = (float)c_near;
+        g.core_div_ok = (n > 0 && sorted[n - 1] <= 16777216.0) ? 1 : 0;          // NaN extents compare false
         // Look up the launch geometry of every build now (code objects load, LDS attributes are set,
         // occupancy is queried), so that no render call after this one has to.
         const int variant = scan_variant(n, n_pad, ntiles);      // the context itself gets its sizes only at the end

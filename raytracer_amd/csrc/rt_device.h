@@ -104,6 +104,8 @@ struct TraceParams {
     int big[kMaxBig];
     float c_near;                          // max |C| over the filtered spheres
     int coop_max;                          // a wave with at most this many live rays tests each ray with all 64 lanes
+    int core_div_ok;                       // every sphere lies within 2^24 of the frame's origin (|C| + r): the exact test may divide by the
+                                           // division's core (rt_trace_impl.h)
     uint32_t width, height;                // full image
     uint32_t npix;                         // owned pixels = owned_rows * width
     int tile_rows, part_index, part_count; // owned row k -> image row, see part_row_at()

@@ -76,6 +76,27 @@ __device__ __forceinline__ float rt_sqrt(float x)
 }
 __device__ __forceinline__ float rt_div(float a, float b) { return a / b; }
 __device__ __forceinline__ float rt_inv_sqrt(float x) { return 1.0f / rt_sqrt_not_tiny(x); }      // callers pass 0 or x >= 1e-15
+// IEEE division.  The compiler's expansion of n / d is: scale both operands if the quotient, the reciprocal or a residual
+// could leave the normal range (v_div_scale_f32 x 2), v_rcp_f32, one Newton step on the reciprocal, the quotient with two
+// residual corrections (the last one v_div_fmas_f32, which undoes the scaling), and v_div_fixup_f32 for zeros,
+// infinities and NaNs: 11 instructions, four of them of the slow kind.  For 2^-40 <= |d| <= 2^40 and
+// 2^-80 <= |n| <= 2^48 nothing is scaled and nothing is fixed up, and the seven fused multiply-adds of the core give the
+// same bits.  The refined reciprocal serves every numerator over the same denominator.
+struct Reciprocal { float d, r; };
+__device__ __forceinline__ Reciprocal div_core_reciprocal(float d)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    Reciprocal k;
+    k.d = d;
+    k.r = __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+    return k;
+}
+__device__ __forceinline__ float div_core(float n, const Reciprocal &k)
+{
+    float q = n * k.r;
+    q = __builtin_fmaf(__builtin_fmaf(-k.d, q, n), k.r, q);
+    return __builtin_fmaf(__builtin_fmaf(-k.d, q, n), k.r, q);
+}
 #else
 __device__ __forceinline__ float rt_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float rt_sqrt_not_tiny(float x) { return __builtin_amdgcn_sqrtf(x); }
@@ -88,6 +109,15 @@ __device__ __forceinline__ V3 unit(V3 v)
 {
     float l2 = lensq(v);
 #if RT_STRICT
+#ifndef RT_LIBM_DIV
+    // 2^-96 <= |v|^2 <= 2^96, or zero: the square root's core and the division's core (1 / len with 2^-48 <= len <= 2^48);
+    // anything else, in any lane of the wave: the compiler's expansions
+    if (__builtin_expect(__ballot(__float_as_uint(l2) - 0x0f800000U > 0x6f800000U - 0x0f800000U && l2 != 0.0f) == 0ULL, 1)) {
+        const float len = sqrt_core(l2);
+        const float inv = div_core(1.0f, div_core_reciprocal(len));
+        return len > 0.0f ? scale(v, inv) : v3(0.0f, 0.0f, 0.0f);
+    }
+#endif
     float len = rt_sqrt(l2);
     if (len > 0.0f) {
         float inv = 1.0f / len;
@@ -336,6 +366,11 @@ __device__ __forceinline__ bool wins_tie(const Probe &q, int i)
 // nearer had been found yet.  Surrounds(root, tmin, closest) fails for the near root either because it is <= tmin,
 // and then the far root is tried, or because it is >= closest, and then the far root, which is not smaller, fails
 // too: the choice of root does not depend on closest.  a = |d|^2 (strict build; the fast build's d is a unit vector).
+// CORE (strict builds): the two quotients by the division's core.  The caller guarantees 2^-40 <= a <= 2^40, an origin within
+// 2^24 of the frame's origin in every coordinate and spheres within 2^24 (rays for which it cannot are tested again with
+// CORE = false): then |h +- sq| <= 2^48, and a numerator below 2^-80 gives a quotient below 2^-40 either way, which
+// tmin = 0.001 rejects either way.
+template <bool CORE = true>
 __device__ __forceinline__ bool sphere_root(const float4 g, float ox, float oy, float oz, float dx, float dy, float dz,
                                             float a, float tmin, float &t)
 {
@@ -346,6 +381,15 @@ __device__ __forceinline__ bool sphere_root(const float4 g, float ox, float oy, 
     const float disc = h * h - a * c;
     if (disc < 0.0f) return false;
     const float sq = rt_sqrt(disc);
+#ifndef RT_LIBM_DIV
+    if (CORE) {
+        const Reciprocal k = div_core_reciprocal(a);
+        float root = div_core(h - sq, k);
+        if (!(tmin < root)) root = div_core(h + sq, k);
+        t = root;
+        return tmin < root;
+    }
+#endif
     float root = (h - sq) / a;
     if (!(tmin < root)) root = (h + sq) / a;
     t = root;
@@ -364,6 +408,7 @@ __device__ __forceinline__ bool sphere_root(const float4 g, float ox, float oy, 
 }
 
 // The accept decision of hit() for sphere i (device order) against the nearest hit found so far.
+template <bool CORE = true>
 __device__ __forceinline__ void exact_test_record(const float4 g, int i, Probe &q)
 {
     float t;
@@ -372,15 +417,16 @@ __device__ __forceinline__ void exact_test_record(const float4 g, int i, Probe &
 #else
     const float a = 1.0f;
 #endif
-    if (sphere_root(g, q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, a, q.tmin, t)) {
+    if (sphere_root<CORE>(g, q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, a, q.tmin, t)) {
         if (t < q.closest) { q.closest = t; q.hit = i; }
         else if (__builtin_expect(t == q.closest, 0)) { if (wins_tie(q, i)) q.hit = i; }
     }
 }
 
+template <bool CORE = true>
 __device__ __forceinline__ void exact_test(const float4 *s_geom, int i, Probe &q)
 {
-    exact_test_record(s_geom[i], i, q);
+    exact_test_record<CORE>(s_geom[i], i, q);
 }
 
 #ifdef RT_DIAG
@@ -1255,10 +1301,14 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
                 if (is_matrix(VARIANT)) scan_spheres_matrix(p, s_geom, s_aimg, s_orig16, pool, lane, q.dx * inv, q.dy * inv, q.dz * inv, q RT_DIAG_PASS);
                 else scan_spheres(p, s_geom, queue, lane, q.dx * inv, q.dy * inv, q.dz * inv, 7.6293945e-6f, q RT_DIAG_PASS);
             }
-            if (!(q.a > 0.0f)) {
-                // a zero or NaN direction gives the filter nothing to work with: test everything
+            // A zero or NaN direction gives the filter nothing to work with, and the exact tests above divide by the
+            // division's core, which is IEEE for 2^-40 <= a <= 2^40, an origin within 2^24 of the frame's origin and spheres
+            // within 2^24 (p.core_div_ok, from the host).  A ray outside that is tested again, against everything, with the
+            // compiler's division.
+            if (!(q.a >= 0x1p-40f && q.a <= 0x1p40f && __builtin_fmaxf(__builtin_fmaxf(fabsf(q.ox), fabsf(q.oy)), fabsf(q.oz)) <= 0x1p24f
+                  && p.core_div_ok != 0)) {
                 q.closest = 3.402823466e+38f; q.hit = -1;
-                for (int i = 0; i < p.n; i++) exact_test(s_geom, i, q);
+                for (int i = 0; i < p.n; i++) exact_test<false>(s_geom, i, q);
             }
         }
 #else
@@ -1314,7 +1364,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
             Probe all = q;
             all.closest = 3.402823466e+38f;
             all.hit = -1;
-            for (int i = 0; i < p.n; i++) exact_test(s_geom, i, all);
+            for (int i = 0; i < p.n; i++) exact_test<false>(s_geom, i, all);     // (with the compiler's division: also checks the short form)
 #if !RT_STRICT
             if (L.zero_dir) all.hit = -1;
 #endif

@@ -15,6 +15,12 @@ VIEWS = {
     "nested": (40, (6.0, 2.0, 5.0), (0.0, 0.0, 0.0), 100.0),
     "far":    (150, (9000.0, 4000.0, 7000.0), (0.0, 0.0, 0.0), 0.1),
     "inside": (60, (0.3, 0.1, -0.2), (5.0, 0.5, 1.0), 100.0),
+    # beyond the range in which the kernel's exact test may use its short form of the IEEE division (a ray's |d|^2 within
+    # 2^-40 .. 2^40, origin and spheres within 2^24 of the origin of coordinates): a scene of huge spheres seen from 2e6
+    # units away (|d|^2 = 4e12 for every camera ray), and the wide scene with one sphere 4e7 units away; both go through
+    # the all-spheres test with the compiler's division
+    "remote": (150, (1.6e6, 0.54e6, 1.06e6), (0.0, 0.0, 0.0), 7.0),
+    "beyond": (300, (120.0, 40.0, 90.0), (0.0, 0.0, 0.0), 100.0),
 }
 
 
@@ -35,6 +41,18 @@ def random_scene(kind, n=None, seed=5):
     elif kind == "far":         # ordinary scene seen from more than 10^4 units away
         s["center"] = r.uniform(-60, 60, (n, 3))
         s["radius"] = r.uniform(1.0, 6.0, n)
+    elif kind == "remote":      # huge spheres seen from 2e6 units away
+        s["center"] = r.uniform(-6e5, 6e5, (n, 3))
+        s["radius"] = r.uniform(1e4, 6e4, n)
+    elif kind == "beyond":      # the wide scene and one sphere 4e7 units below it
+        s["center"] = r.uniform(-50, 50, (n, 3))
+        s["radius"] = r.uniform(0.5, 5.0, n)
+        s["center"][0] = (0, -5000, 0)
+        s["radius"][0] = 4950.0
+        s["center"][1] = (30, 10, -400)
+        s["radius"][1] = 300.0
+        s["center"][2] = (0, -4.0e7, 0)
+        s["radius"][2] = 1.0e7
     elif kind == "inside":      # the eye sits inside many overlapping spheres of very different sizes
         s["center"] = r.normal(0, 1.5, (n, 3))
         s["radius"] = np.exp(r.uniform(np.log(0.3), np.log(40.0), n))
