@@ -197,6 +197,7 @@ class MockRt:
         st.chunk_spp = self.chunk_for(W, H, spp, chunk_spp)
         st.wave_scans = st.rays // 64
         st.scan_tiles = (self.n + 31) // 32
+        st.tile_products = st.wave_scans * st.scan_tiles // 2           # as if the cull skipped every other tile
         return st
 
 
@@ -382,7 +383,7 @@ def main():
         vector FP32 peak (a speed-up measure: it exceeds 1, it is not a roofline)."""
         ms = float(np.mean([s.kernel_ms for s in sts]))
         tests = float(np.mean([s.sphere_tests for s in sts]))
-        mflop = float(np.mean([float(s.wave_scans) * float(s.scan_tiles) * MFMA_PER_TILE * FLOP_PER_MFMA for s in sts]))
+        mflop = float(np.mean([float(s.tile_products) * MFMA_PER_TILE * FLOP_PER_MFMA for s in sts]))
         return {"kernel_ms": ms, "tests": tests, "matrix_flop": mflop,
                 "matrix_tflops": mflop / (ms * 1e-3) / 1e12,
                 "algorithmic_tflops": FLOP_PER_TEST * tests / (ms * 1e-3) / 1e12}
@@ -403,13 +404,18 @@ def main():
         if on_matrix:
             # The ray-sphere tests run on the matrix cores (one 32-term f16 inner product per test, f32 accumulation;
             # the vector ALU compares and runs the exact f32 test on what passes), so that is the roofline: executed
-            # matrix flop (4 instructions of 32768 flop per 32-sphere tile and wave scan, padding rows included,
+            # matrix flop (4 instructions of 32768 flop per 32-sphere tile a wave scan multiplies, padding rows included,
             # counted by the kernel; SQ_INSTS_VALU_MFMA_MOPS_F16 x 512 of the committed counter pass agrees) per
-            # second of kernel time against the dense f16 peak.
+            # second of kernel time against the dense f16 peak.  A scan skips the tiles whose bounding box none of its
+            # rays meets, so fewer flop are executed for the same result: the fraction measures the pipe's use, the
+            # metric (samples per second) the result.
             roof = {"bound": "mfma", "resource": "f16 matrix cores (v_mfma_f32_32x32x16_f16)",
                     "achieved": round(rates["matrix_tflops"], 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(rates["matrix_tflops"] / PEAK_F16_MFMA_TFLOPS, 4),
-                    "numerator": "executed matrix flop (wave scans x tiles x 4 MFMA x 32768) / kernel time",
+                    "numerator": "executed matrix flop (tiles multiplied x 4 MFMA x 32768; a wave scan multiplies only the tiles "
+                                 "whose bounding box one of its rays meets) / kernel time",
+                    "tiles_multiplied_per_wave_scan": round(float(np.mean([float(s.tile_products) / max(float(s.wave_scans), 1.0) for s in stats])), 3),
+                    "tiles_per_scene": int(stats[-1].scan_tiles),
                     "matrix_flop_per_launch": rates["matrix_flop"],
                     "matrix_flop_per_launch_from_counters": busy.get("mfma_flop_per_launch")}
         else:

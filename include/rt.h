@@ -105,9 +105,12 @@ typedef struct rt_stats {
     uint32_t chunk_spp;      /* samples per work unit used (the choice made for RT_CHUNK_AUTO) */
     uint32_t scan_tiles;     /* 32-sphere tiles one sphere scan of a wave multiplies on the
                                 matrix cores (0: the scene runs the packed-FP32 scan)        */
-    uint64_t wave_scans;     /* sphere scans run (64 rays against all spheres each); with
-                                scan_tiles the executed matrix work of the call:
-                                wave_scans * scan_tiles * 4 instructions of 32768 flop     */
+    uint64_t wave_scans;     /* sphere scans run (64 rays against all spheres each)        */
+    uint64_t tile_products;  /* tiles those scans multiplied on the matrix cores: a scan
+                                skips the tiles whose bounding box none of its rays meets,
+                                so this is at most wave_scans * scan_tiles.  The executed
+                                matrix work of the call is tile_products * 4 instructions
+                                of 32768 flop                                              */
 } rt_stats;
 
 enum { RT_CHUNK_AUTO = -1 };  /* rt_opts.chunk_spp: let the library choose the unit size */

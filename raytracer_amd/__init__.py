@@ -45,7 +45,8 @@ class CameraParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("resolve_ms", C.c_double),
-                ("chunk_spp", C.c_uint32), ("scan_tiles", C.c_uint32), ("wave_scans", C.c_uint64)]
+                ("chunk_spp", C.c_uint32), ("scan_tiles", C.c_uint32), ("wave_scans", C.c_uint64),
+                ("tile_products", C.c_uint64)]
 
 
 class Opts(C.Structure):

@@ -75,7 +75,7 @@ struct Ctx {
     int big[kMaxBig] = {0};
     float c_near = 0.0f;
     int core_div_ok = 0;         // every sphere within 2^24 of the origin (TraceParams::core_div_ok)
-    DevBuf geom, matA, matB, pairs, aimg, orig, tbounds;
+    DevBuf geom, matA, matB, pairs, aimg, orig, tbounds, tboxes;
     int ntiles = 0;              // 32-sphere tiles of the matrix scan's image (0: the scene is too large for it)
     float mat_scale = 1.0f;      // power-of-two scale of the matrix scan's frame
     // scratch
@@ -419,6 +419,8 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             tp.pairs = (const float *)g.pairs.p;
             tp.aimg = (const uint4 *)g.aimg.p; tp.ntiles = g.ntiles;
             tp.tile_bounds = g.ntiles > 0 ? (const float4 *)g.tbounds.p : nullptr;
+            tp.tile_boxes = (g.ntiles > 0 && !getenv("RTMI_NO_CULL")) ? (const float4 *)g.tboxes.p : nullptr;      // (RTMI_NO_CULL: comparison runs)
+            tp.box_margin = 1.0f / 512.0f;
             tp.mat_scale = g.mat_scale; tp.mat_c_near = g.c_near * g.mat_scale;
             tp.n = g.n; tp.n_pad = g.n_pad;
             tp.nbig = g.nbig; memcpy(tp.big, g.big, sizeof tp.big); tp.c_near = g.c_near; tp.core_div_ok = g.core_div_ok;
@@ -520,6 +522,7 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             st.rays = c[1];
             st.wave_scans = c[19];
             st.scan_tiles = is_matrix(scan_variant(g)) ? (uint32_t)g.ntiles : 0;
+            st.tile_products = c[22];
 #ifdef RT_DIAG
             fprintf(stderr, "diag: wave scans %llu; per wave scan: pair branches taken %.1f, filter passes %.1f, "
                     "queued candidates %.2f, drain iterations %.2f, live lanes %.1f; rays traced in shared-ray mode %llu of %llu; "
@@ -529,8 +532,9 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
 #ifndef RT_DIAG_STAMPS
             if (g.ntiles > 0 && c[5] > 0)
                 fprintf(stderr, "diag: of %d tiles per wave scan, %.2f have a bounding sphere some live ray passes; of %d (tile, half of the wave's rays) "
-                        "pairs %.2f; of %d (16-sphere half tile, half of the rays) pairs %.2f\n", g.ntiles, (double)c[9] / c[5], 2 * g.ntiles,
-                        (double)c[10] / c[5], 4 * g.ntiles, (double)c[15] / c[5]);
+                        "pairs %.2f; of %d (16-sphere half tile, half of the rays) pairs %.2f; with the tiles' axis-aligned boxes instead: %.2f tiles, "
+                        "%.2f (tile, half) pairs; tiles multiplied %.2f\n", g.ntiles, (double)c[9] / c[5], 2 * g.ntiles,
+                        (double)c[10] / c[5], 4 * g.ntiles, (double)c[15] / c[5], (double)c[16] / c[5], (double)c[17] / c[5], (double)c[18] / c[5]);
             if (c[5] > 0)
                 fprintf(stderr, "diag: share of the wave scans with 5-8 / 9-16 / 17-32 / 33-48 live rays: %.1f / %.1f / %.1f / %.1f %%\n",
                         100.0 * c[11] / c[5], 100.0 * c[12] / c[5], 100.0 * c[13] / c[5], 100.0 * c[14] / c[5]);
@@ -568,7 +572,7 @@ void release_ctx(Ctx &g)
     (void)hipSetDevice(g.device);
     if (g.stream) (void)hipStreamSynchronize(g.stream);
     g.geom.release(); g.matA.release(); g.matB.release(); g.pairs.release();
-    g.aimg.release(); g.tbounds.release();
+    g.aimg.release(); g.tbounds.release(); g.tboxes.release();
     g.orig.release();
     g.partial.release(); g.running.release(); g.rows.release(); g.counters.release(); g.rgba.release(); g.accum.release(); g.hit.release();
     if (g.ev0) (void)hipEventDestroy(g.ev0);
@@ -985,8 +989,17 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
     // memory on one device, say) must not leave new scalars next to old buffers, or some contexts on the new
     // world and others on the old one; rt_render then reports RT_ERR_STATE until rt_set_world succeeds.
     // bounding spheres of the tiles (diagnostic build: how many tiles a coarser test could skip)
-    std::vector<float4> tbounds((size_t)std::max(1, ntiles) * 3, make_float4(0.0f, 0.0f, 0.0f, -1.0f));
-    for (int t = 0; t < ntiles; t++)
+    // [tile][5]: bounding sphere of the tile, of its two 16-sphere halves, and the tile's axis-aligned box (lo, hi)
+    std::vector<float4> tbounds((size_t)std::max(1, ntiles) * 5, make_float4(0.0f, 0.0f, 0.0f, -1.0f));
+    for (int t = 0; t < ntiles; t++) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (int i = t * kTileSpheres; i < std::min(n, (t + 1) * kTileSpheres); i++)
+            if (!is_big[i]) {
+                const double cc[3] = {spheres[i].center.x, spheres[i].center.y, spheres[i].center.z}, rr = std::fabs((double)spheres[i].radius) * 1.0001 + 1e-4;
+                for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], cc[a] - rr); hi[a] = std::max(hi[a], cc[a] + rr); }
+            }
+        tbounds[(size_t)t * 5 + 3] = make_float4((float)lo[0], (float)lo[1], (float)lo[2], lo[0] <= hi[0] ? 1.0f : -1.0f);
+        tbounds[(size_t)t * 5 + 4] = make_float4((float)hi[0], (float)hi[1], (float)hi[2], 0.0f);
         for (int part = 0; part < 3; part++) {
             const int i0 = t * kTileSpheres + (part == 2 ? 16 : 0), i1 = std::min(n, t * kTileSpheres + (part == 1 ? 16 : 32));
             double c[3] = {0, 0, 0};
@@ -1001,8 +1014,31 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
                     const double dx = spheres[i].center.x - c[0], dy = spheres[i].center.y - c[1], dz = spheres[i].center.z - c[2];
                     rad = std::max(rad, std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs((double)spheres[i].radius));
                 }
-            tbounds[(size_t)t * 3 + part] = make_float4((float)c[0], (float)c[1], (float)c[2], (float)(rad * 1.0001));
+            tbounds[(size_t)t * 5 + part] = make_float4((float)c[0], (float)c[1], (float)c[2], (float)(rad * 1.0001));
         }
+    }
+    // Axis-aligned boxes of the tiles' filtered spheres as {centre, half extents}: the matrix scan multiplies a tile only if
+    // the box meets a live ray of the wave (rt_trace_impl.h).  Rounded outwards; a tile without filtered spheres gets a
+    // box nothing meets.
+    std::vector<float4> tboxes((size_t)std::max(1, ntiles) * 2, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    for (int t = 0; t < ntiles; t++) {
+        const float4 lo = tbounds[(size_t)t * 5 + 3], hi = tbounds[(size_t)t * 5 + 4];
+        if (!(lo.w > 0.0f)) {
+            const float ninf = -std::numeric_limits<float>::infinity();
+            tboxes[(size_t)t * 2 + 1] = make_float4(ninf, ninf, ninf, 0.0f);
+            continue;
+        }
+        const double c[3] = {0.5 * ((double)lo.x + hi.x), 0.5 * ((double)lo.y + hi.y), 0.5 * ((double)lo.z + hi.z)};
+        const float cf[3] = {(float)c[0], (float)c[1], (float)c[2]};
+        float hf[3];
+        const double l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
+        for (int a = 0; a < 3; a++) {
+            const double half = std::max(h[a] - (double)cf[a], (double)cf[a] - l[a]);      // about the rounded centre
+            hf[a] = std::nextafter((float)half, std::numeric_limits<float>::infinity());
+        }
+        tboxes[(size_t)t * 2] = make_float4(cf[0], cf[1], cf[2], 0.0f);
+        tboxes[(size_t)t * 2 + 1] = make_float4(hf[0], hf[1], hf[2], 0.0f);
+    }
     for (int k = 0; k < g_nctx; k++) { g_ctx[k].n_pad = 0; g_ctx[k].n = 0; }
     for (int k = 0; k < g_nctx; k++) {
         Ctx &g = g_ctx[k];
@@ -1014,6 +1050,8 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
             HIP_TRY(g.aimg.reserve(aimg.size() * sizeof(uint16_t)));
             HIP_TRY(hipMemcpy(g.aimg.p, aimg.data(), aimg.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         }
+        HIP_TRY(g.tboxes.reserve(tboxes.size() * sizeof(float4)));
+        HIP_TRY(hipMemcpy(g.tboxes.p, tboxes.data(), tboxes.size() * sizeof(float4), hipMemcpyHostToDevice));
         HIP_TRY(g.tbounds.reserve(tbounds.size() * sizeof(float4)));
         HIP_TRY(hipMemcpy(g.tbounds.p, tbounds.data(), tbounds.size() * sizeof(float4), hipMemcpyHostToDevice));
         HIP_TRY(g.pairs.reserve(pairs.size() * sizeof(float)));

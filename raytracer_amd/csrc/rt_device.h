@@ -70,10 +70,10 @@ constexpr int kMatListCap = 63 + 1024 + 1;
 constexpr int kMatWaveBytes = kMatKeyBytes + kMatListCap * 4;
 static_assert(kMatWaveBytes % 16 == 0, "the wave regions stay 16-byte aligned");
 // LDS of the matrix scan with its images staged: [sphere image 2 KB per tile][geometry 16 B per sphere]
-// [caller's index 2 B per sphere][wave regions]
+// [caller's index 2 B per sphere][tile boxes 32 B per tile][wave regions]
 inline size_t matrix_lds_bytes(int n_pad, int ntiles)
 {
-    return (size_t)ntiles * 128 * 16 + (size_t)n_pad * 16 + (size_t)n_pad * 2 + (size_t)(kMatBlockThreads / 64) * kMatWaveBytes;
+    return (size_t)ntiles * 128 * 16 + (size_t)n_pad * 16 + (size_t)n_pad * 2 + (size_t)ntiles * 32 + (size_t)(kMatBlockThreads / 64) * kMatWaveBytes;
 }
 constexpr int kMaxTilesMatrix = 32;        // what fits beside the wave regions of 16 waves (the host checks matrix_lds_bytes)
 constexpr int kMaxSpheresMatrix = kMaxTilesMatrix * kTileSpheres;
@@ -94,8 +94,11 @@ struct TraceParams {
     const int32_t *orig;                   // [n_pad] device order -> index in the caller's list (hit indices, ties)
     const float *pairs;                    // [n_pad / 2][8]
     const uint4 *aimg;                     // [ntiles][2][64] f16 fragments of the matrix scan, or nullptr
-    const float4 *tile_bounds;             // [ntiles][3] bounding spheres {centre, radius} of a tile's filtered spheres and of its two
+    const float4 *tile_bounds;             // [ntiles][5] bounding spheres {centre, radius} of a tile's filtered spheres and of its two
                                            // 16-sphere halves (radius < 0: empty); read by the diagnostic build only
+    const float4 *tile_boxes;              // [ntiles][2] axis-aligned box {centre, half extents} of a tile's filtered spheres (the matrix scan
+                                           // skips the tiles whose box no live ray of the wave meets), or nullptr
+    float box_margin;                      // by how much a ray widens every box, per unit of |O| + max |C|
     float mat_scale;                       // power-of-two scale of the matrix scan's frame
     float mat_c_near;                      // max |C| over the filtered spheres, in that frame
     int ntiles;
@@ -116,7 +119,8 @@ struct TraceParams {
     uint32_t seed, sample_base;
     float4 *partial;                       // [nchunks][npix] per-chunk colour sums
     int32_t *hit_index;                    // [npix] compact, or nullptr
-    unsigned long long *counters;          // [0] next work unit, [1] rays cast, [19] sphere scans run by the waves ([2..18]: diagnostic build)
+    unsigned long long *counters;          // [0] next work unit, [1] rays cast, [19] sphere scans run by the waves, [22] tiles they multiplied
+                                           // ([2..18], [20], [21]: diagnostic builds)
     unsigned long long total_units;        // npix * nchunks
 };
 

@@ -434,7 +434,7 @@ __device__ __forceinline__ void exact_test(const float4 *s_geom, int i, Probe &q
 // all spheres per ray (lost_hits); RT_DIAG_STAMPS adds shader-clock stamps at the phase boundaries of
 // the main loop (wave-cycles per phase, summed over waves; a stamp drains the scalar-memory queue).
 struct Diag {
-    uint32_t branches, passes, drain_iters, drain_lanes, scans, scan_lanes, shared_rays, lost_hits, tiles_bound, tiles_halfbound, quads_bound;
+    uint32_t branches, passes, drain_iters, drain_lanes, scans, scan_lanes, shared_rays, lost_hits, tiles_bound, tiles_halfbound, quads_bound, tiles_box, pairs_box, tiles_run;
     uint32_t scans_by_live[4];      // wave scans with at most 8 / 16 / 32 / 48 live rays
     unsigned long long t_handout, t_regen, t_hit, t_drain, t_big, t_shade, t_shared, t_feat, t_append;
 };
@@ -688,8 +688,21 @@ __device__ __forceinline__ void queue_passes(const f32x16 &acc, const RowMaxima 
 // candidates are few and unevenly spread over the lanes (about one per ray, up to five or six), so lane-private
 // queues kept four lanes in five idle during their exact tests.  A lane fetches the ray of its entry from the
 // registers of the lane that owns it and lowers that ray's key in LDS; every lane reads its own key afterwards.
+//
+// Before a tile is multiplied the wave asks whether any of its live rays can meet the tile at all: a slab test of the ray
+// (from its origin to the nearest hit the big spheres already gave) against the axis-aligned box of the tile's spheres.
+// The spheres of a tile are neighbours in space (device order), so most tiles lie off the paths of all 64 rays: of the
+// final scene's 16 tiles a wave multiplies 7.4.  The test must never drop a sphere the exact test would accept.  That test
+// accepts a sphere whose centre lies within sqrt(r^2 + E) of the ray's line, E <= 2^-21 S^2 being the rounding of its
+// discriminant per unit |d|^2 (S = |O| + max |C|): every box is widened by 2^-9 S for the ray at hand (eight times E in
+// the square), which also covers the slab arithmetic (hardware reciprocal, one FMA per plane: 2^-22 of the coordinates).
+// A zero component of d makes the planes of that axis infinite or NaN; maxima and minima drop NaNs and a NaN interval
+// counts as a meeting, so that axis constrains nothing.  `live`: the lane carries a ray.
+// ONE_GROUP: the scene has at most 64 tiles (always so with the images in LDS), one mask holds them all.
+template <bool ONE_GROUP>
 __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const float4 *s_geom, const uint4 *s_aimg, const uint16_t *s_orig16,
-                                                    char *pool_base, int lane, float ux, float uy, float uz, Probe &q RT_DIAG_ARG)
+                                                    const float4 *s_box, char *pool_base, int lane, bool live, float ux, float uy, float uz,
+                                                    Probe &q, uint32_t &tiles_done RT_DIAG_ARG)
 {
     RT_MARK("scan_begin_big");
     const WavePool w = wave_pool(pool_base);
@@ -708,6 +721,44 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
     asm volatile("" : "+v"(ux), "+v"(uy), "+v"(uz));          // the feature arithmetic stays between its two stamps
 #endif
 #endif
+    // ---- which tiles of a group of 64 does any live ray of the wave meet?  (The first group is settled here, before the ray
+    // features and their fragments occupy registers.)
+#ifdef RT_NO_BOX_CULL          // comparison build: every tile is multiplied
+    const bool cull = false;
+#else
+    const bool cull = s_box != nullptr;
+#endif
+    const unsigned long long live_lanes = __ballot(live);
+    auto tiles_in_need = [&](int t0) {
+        const int group = p.ntiles - t0 < 64 ? p.ntiles - t0 : 64;
+        if (!cull) return group == 64 ? ~0ULL : (1ULL << group) - 1ULL;
+        // the ray in the form the slab test wants: t of the plane x = c is c * (1 / dx) - ox * (1 / dx)
+        const float ix = __builtin_amdgcn_rcpf(q.dx), iy = __builtin_amdgcn_rcpf(q.dy), iz = __builtin_amdgcn_rcpf(q.dz);
+        const float oix = q.ox * ix, oiy = q.oy * iy, oiz = q.oz * iz;
+        const float wo = fmaf(q.oz, q.oz, fmaf(q.oy, q.oy, q.ox * q.ox));
+        const float widen = fmaf(__builtin_amdgcn_sqrtf(wo), 1.0000005f, p.c_near) * p.box_margin;          // 2^-9 (|O| + max |C|)
+        auto meets = [&](int t) {                          // lanes whose ray meets the box of tile t
+            const float4 bc = s_box[2 * t], bh = s_box[2 * t + 1];
+            const float hx = bh.x + widen, hy = bh.y + widen, hz = bh.z + widen;
+            const float mx = __builtin_fmaf(bc.x, ix, -oix), my = __builtin_fmaf(bc.y, iy, -oiy), mz = __builtin_fmaf(bc.z, iz, -oiz);
+            const float nx = __builtin_fmaf(-hx, fabsf(ix), mx), ny = __builtin_fmaf(-hy, fabsf(iy), my), nz = __builtin_fmaf(-hz, fabsf(iz), mz);
+            const float fx = __builtin_fmaf(hx, fabsf(ix), mx), fy = __builtin_fmaf(hy, fabsf(iy), my), fz = __builtin_fmaf(hz, fabsf(iz), mz);
+            const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx, ny), nz), 0.0f);
+            const float t_out = __builtin_fminf(__builtin_fminf(__builtin_fminf(fx, fy), fz), q.closest);
+            return __ballot(!(t_out < t_in)) & live_lanes;
+        };
+        // from the last tile of the group to the first, the mask shifted up by one per tile; four tiles per step, so that
+        // their box reads are in flight together
+        unsigned long long need = 0ULL;
+        int k = group;
+        for (; k >= 4; k -= 4) {
+            const unsigned long long m3 = meets(t0 + k - 1), m2 = meets(t0 + k - 2), m1 = meets(t0 + k - 3), m0 = meets(t0 + k - 4);
+            need = (need << 4) | (m3 != 0ULL ? 8ULL : 0ULL) | (m2 != 0ULL ? 4ULL : 0ULL) | (m1 != 0ULL ? 2ULL : 0ULL) | (m0 != 0ULL ? 1ULL : 0ULL);
+        }
+        for (; k >= 1; k--) need = (need << 1) | (meets(t0 + k - 1) != 0ULL ? 1ULL : 0ULL);
+        return need;
+    };
+    const unsigned long long need_first = tiles_in_need(0);
     RT_MARK("features");
     // ray features in the frame scaled by p.mat_scale (a power of two)
     const float ox = q.ox * p.mat_scale, oy = q.oy * p.mat_scale, oz = q.oz * p.mat_scale;
@@ -979,13 +1030,34 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
         compare(acc0, acc1, x, t);
     };
     f16x8 a[2], b[2];
-    read_tile(a, tile);
-    for (int t = 0; t < p.ntiles; t += 2, tile += 256) {
-        read_tile(b, tile + 128);
-        do_tile(a, t);
-        if (t + 1 < p.ntiles) {
-            read_tile(a, tile + 256);
-            do_tile(b, t + 1);
+    for (int t0 = 0; t0 < (ONE_GROUP ? 1 : p.ntiles); t0 += 64) {
+        unsigned long long need = t0 == 0 ? need_first : tiles_in_need(t0);
+#ifdef RT_X_CULL_IGNORE        // marginal-cost experiment: the masks are computed and every tile is multiplied all the same
+        asm volatile("" : "+s"(need));
+        need |= (p.ntiles - t0 < 64) ? (1ULL << (p.ntiles - t0)) - 1ULL : ~0ULL;
+#endif
+#ifdef RT_DIAG
+        dg.tiles_run += (uint32_t)__popcll(need);
+#endif
+        tiles_done += (uint32_t)__popcll(need);
+        if (need == 0ULL) continue;
+        // the tiles in need, two fragment buffers used in turn: the next tile's fragments are read before this tile's products are issued
+        // (every step reads fragments, the last one the tile it already has: a read inside a branch would make the compiler wait
+        // for ALL outstanding LDS reads ahead of the products, the ones just issued for the next tile included)
+        auto next_tile = [&](int now) { const int k = need != 0ULL ? t0 + __ffsll((long long)need) - 1 : now; need &= need - 1ULL; return k; };
+        int t = next_tile(0);
+        read_tile(a, tile + t * 128);
+        for (;;) {
+            const bool more_b = need != 0ULL;
+            const int t2 = next_tile(t);
+            read_tile(b, tile + t2 * 128);
+            do_tile(a, t);
+            if (!more_b) break;
+            const bool more_a = need != 0ULL;
+            t = next_tile(t2);
+            read_tile(a, tile + t * 128);
+            do_tile(b, t2);
+            if (!more_a) break;
         }
     }
 #endif
@@ -1138,6 +1210,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
     uint32_t *queue;
     const uint4 *s_aimg = nullptr;
     const uint16_t *s_orig16 = nullptr;
+    const float4 *s_box = nullptr;
     char *pool = nullptr;
     if (VARIANT == kScanMatrix) {
         uint4 *img = reinterpret_cast<uint4 *>(lds);                       // [ntiles][2][64]
@@ -1146,12 +1219,17 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
         for (int i = threadIdx.x; i < p.n_pad; i += blockDim.x) gm[i] = p.geom[i];
         uint16_t *o16 = reinterpret_cast<uint16_t *>(gm + p.n_pad);        // [n_pad] caller's indices (below 65536 here)
         for (int i = threadIdx.x; i < p.n_pad; i += blockDim.x) o16[i] = (uint16_t)p.orig[i];
+        float4 *bx = reinterpret_cast<float4 *>(o16 + p.n_pad);            // [ntiles][2] tile boxes (n_pad is a multiple of 8: 16-byte aligned)
+        if (p.tile_boxes != nullptr)
+            for (int i = threadIdx.x; i < p.ntiles * 2; i += blockDim.x) bx[i] = p.tile_boxes[i];
         s_aimg = img; s_geom = gm; s_orig16 = o16;
+        s_box = p.tile_boxes != nullptr ? bx : nullptr;
         s_matA = p.matA; s_matB = p.matB;
-        pool = reinterpret_cast<char *>(o16 + p.n_pad) + (threadIdx.x >> 6) * kMatWaveBytes;
+        pool = reinterpret_cast<char *>(bx + p.ntiles * 2) + (threadIdx.x >> 6) * kMatWaveBytes;
         queue = nullptr;
     } else if (VARIANT == kScanMatrixGlobal) {
         s_aimg = p.aimg; s_geom = p.geom; s_matA = p.matA; s_matB = p.matB;
+        s_box = p.tile_boxes;
         pool = reinterpret_cast<char *>(lds) + (threadIdx.x >> 6) * kMatWaveBytes;
         queue = nullptr;
     } else if (VARIANT == kScanVectorGlobal) {
@@ -1183,6 +1261,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
     bool need_sample = true;   // lane must start a new sample
     uint32_t rays = 0;
     uint32_t wave_scans = 0;   // times this wave ran the sphere scan (wave-uniform)
+    uint32_t tiles_done = 0;   // tiles it multiplied in those scans (wave-uniform)
     const uint32_t waves_per_block = blockDim.x >> 6;
     const uint32_t pool_units = (uint32_t)p.pool_units;    // work units a wave takes from the global counter at a time
     const unsigned long long static_units = (unsigned long long)gridDim.x * waves_per_block * pool_units;
@@ -1192,7 +1271,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
     pool_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_next);       // wave-uniform by construction
     pool_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_end);
 #ifdef RT_DIAG
-    Diag dg = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
+    Diag dg = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
     const unsigned long long t_wave0 = RT_STAMP();
     (void)t_wave0;
 #endif
@@ -1298,7 +1377,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
             if (__popcll(live) <= p.coop_max) shared_ray_hit(p, s_geom, lane, live, q);
             else {
                 wave_scans++;
-                if (is_matrix(VARIANT)) scan_spheres_matrix(p, s_geom, s_aimg, s_orig16, pool, lane, q.dx * inv, q.dy * inv, q.dz * inv, q RT_DIAG_PASS);
+                if (is_matrix(VARIANT)) scan_spheres_matrix<VARIANT == kScanMatrix>(p, s_geom, s_aimg, s_orig16, s_box, pool, lane, active, q.dx * inv, q.dy * inv, q.dz * inv, q, tiles_done RT_DIAG_PASS);
                 else scan_spheres(p, s_geom, queue, lane, q.dx * inv, q.dy * inv, q.dz * inv, 7.6293945e-6f, q RT_DIAG_PASS);
             }
             // A zero or NaN direction gives the filter nothing to work with, and the exact tests above divide by the
@@ -1316,7 +1395,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
         if (__popcll(live) <= p.coop_max) shared_ray_hit(p, s_geom, lane, live, q);
         else {
             wave_scans++;
-            if (is_matrix(VARIANT)) scan_spheres_matrix(p, s_geom, s_aimg, s_orig16, pool, lane, q.dx, q.dy, q.dz, q RT_DIAG_PASS);
+            if (is_matrix(VARIANT)) scan_spheres_matrix<VARIANT == kScanMatrix>(p, s_geom, s_aimg, s_orig16, s_box, pool, lane, active, q.dx, q.dy, q.dz, q, tiles_done RT_DIAG_PASS);
             else scan_spheres(p, s_geom, queue, lane, q.dx, q.dy, q.dz, 1.9073486e-6f, q RT_DIAG_PASS);   // 2^-19
         }
         if (L.zero_dir) q.hit = -1;
@@ -1351,11 +1430,24 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
             for (int t = 0; t < p.ntiles; t++) {
                 // ... and per half of the wave's rays (the 32 columns of one matrix product): (tile, ray half) pairs of 2 per tile,
                 // (16-sphere half tile, ray half) pairs of 4 per tile
-                const unsigned long long m = __ballot(passes(p.tile_bounds[3 * t]));
+                const unsigned long long m = __ballot(passes(p.tile_bounds[5 * t]));
                 if (m != 0ULL) dg.tiles_bound++;
                 dg.tiles_halfbound += ((uint32_t)m != 0U) + ((uint32_t)(m >> 32) != 0U);
-                const unsigned long long m1 = __ballot(passes(p.tile_bounds[3 * t + 1])), m2 = __ballot(passes(p.tile_bounds[3 * t + 2]));
+                const unsigned long long m1 = __ballot(passes(p.tile_bounds[5 * t + 1])), m2 = __ballot(passes(p.tile_bounds[5 * t + 2]));
                 dg.quads_bound += ((uint32_t)m1 != 0U) + ((uint32_t)(m1 >> 32) != 0U) + ((uint32_t)m2 != 0U) + ((uint32_t)(m2 >> 32) != 0U);
+                // the same with the tile's axis-aligned box (slab test; NaNs count as a pass)
+                const float4 blo = p.tile_bounds[5 * t + 3], bhi = p.tile_bounds[5 * t + 4];
+                bool in_box = false;
+                if (blo.w > 0.0f && active) {
+                    const float ax0 = (blo.x - q.ox) / q.dx, ax1 = (bhi.x - q.ox) / q.dx, ay0 = (blo.y - q.oy) / q.dy, ay1 = (bhi.y - q.oy) / q.dy;
+                    const float az0 = (blo.z - q.oz) / q.dz, az1 = (bhi.z - q.oz) / q.dz;
+                    const float tn = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), 0.0f));
+                    const float tf = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
+                    in_box = !(tf < tn);
+                }
+                const unsigned long long mb = __ballot(in_box);
+                dg.tiles_box += (mb != 0ULL);
+                dg.pairs_box += ((uint32_t)mb != 0U) + ((uint32_t)(mb >> 32) != 0U);
             }
         }
         {
@@ -1534,6 +1626,7 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
     if (__lane_id() == 0) {
         atomicAdd(&p.counters[1], r64);
         atomicAdd(&p.counters[19], (unsigned long long)wave_scans);
+        atomicAdd(&p.counters[22], (unsigned long long)tiles_done);
     }
 #ifdef RT_DIAG
     if (__lane_id() == 0) {
@@ -1547,6 +1640,9 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
         atomicAdd(&p.counters[9], (unsigned long long)dg.tiles_bound);
         atomicAdd(&p.counters[10], (unsigned long long)dg.tiles_halfbound);
         atomicAdd(&p.counters[15], (unsigned long long)dg.quads_bound);
+        atomicAdd(&p.counters[16], (unsigned long long)dg.tiles_box);
+        atomicAdd(&p.counters[17], (unsigned long long)dg.pairs_box);
+        atomicAdd(&p.counters[18], (unsigned long long)dg.tiles_run);
         for (int k = 0; k < 4; k++) atomicAdd(&p.counters[11 + k], (unsigned long long)dg.scans_by_live[k]);
 #endif
     }

@@ -50,7 +50,9 @@ def test_two_rank_json_shape():
     # the roofline is a fraction of a physical peak: executed matrix flop against the dense f16 peak
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
     assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / 2500.0) < 1e-3
-    assert r["matrix_flop_per_launch"] == r["wave_scans_per_launch"] * 16 * 4 * 32768       # 488 spheres = 16 tiles
+    assert r["tiles_per_scene"] == 16                                                        # 488 spheres = 16 tiles
+    assert r["matrix_flop_per_launch"] == r["wave_scans_per_launch"] * r["tiles_multiplied_per_wave_scan"] * 4 * 32768
+    assert 0 < r["tiles_multiplied_per_wave_scan"] <= 16
     assert r["traffic"] is None and r["traffic_ratio"] is None
     for key in ("valu_issue_busy", "mfma_busy", "lane_occupation", "vector_instr_per_wave_scan", "algorithmic_vs_vector_peak"):
         assert key in out                                              # flat keys, null without a counter pass
