@@ -92,6 +92,7 @@ Ctx g_ctx[kMaxContexts];
 int g_nctx = 0;
 bool g_vector_scan = false;      // RTMI_SCAN=vector in the environment at rt_init: packed-FP32 scan for every scene size
 bool g_caller_order = false;     // RTMI_ORDER=caller in the environment at rt_init: spheres stay in the caller's order on the device (comparison runs)
+bool g_curve_order = false;      // RTMI_ORDER=curve: along the Z-order curve only, tiles not split in space (comparison runs)
 
 thread_local char g_err[512] = "";      // per thread: the worker threads of a multi-device frame report through it
 
@@ -772,6 +773,7 @@ int rt_init_devices(const int *devices, int count)
         g_vector_scan = scan && strcmp(scan, "vector") == 0;
         const char *ord = getenv("RTMI_ORDER");
         g_caller_order = ord && strcmp(ord, "caller") == 0;
+        g_curve_order = ord && strcmp(ord, "curve") == 0;
         if (!devices || count < 1 || count > kMaxContexts)
             return fail(RT_ERR_ARG, "rt_init_devices: between 1 and %d devices (got %d)", kMaxContexts, count);
         int ndev = 0;
@@ -851,18 +853,93 @@ static std::vector<int32_t> device_order(const rt_sphere *spheres, int n)
     // scene ran 4 % slower (239.5 against 230.4 ms); 64 cells: 234.2 ms
     const double cells = 1024.0;
     std::vector<uint32_t> key(n, 0xffffffffU);
+    std::vector<uint32_t> cell((size_t)n * 3, 1023U);
     for (int i = 0; i < n; i++) {
-        uint32_t cell[3];
         bool ok = true;
         for (int a = 0; a < 3; a++) {
             const double c = coord(i, a);
             if (!std::isfinite(c)) { ok = false; break; }
             const double q = (c - lo[a]) / span * cells;
-            cell[a] = (uint32_t)std::min(cells - 1.0, std::max(0.0, q));
+            cell[(size_t)i * 3 + a] = (uint32_t)std::min(cells - 1.0, std::max(0.0, q));
         }
-        if (ok) key[i] = morton3(cell[0], cell[1], cell[2]);
+        if (ok) key[i] = morton3(cell[(size_t)i * 3], cell[(size_t)i * 3 + 1], cell[(size_t)i * 3 + 2]);
+        else cell[(size_t)i * 3] = cell[(size_t)i * 3 + 1] = cell[(size_t)i * 3 + 2] = 1023U;
     }
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+    auto along_curve = [&](int32_t a, int32_t b) { return key[a] < key[b]; };
+    std::stable_sort(order.begin(), order.end(), along_curve);
+    if (g_curve_order || n <= kTileSpheres) return order;
+    // Tiles as boxes: the matrix scan skips a tile whose bounding box no ray of the wave meets (rt_trace_impl.h), and
+    // 32 consecutive spheres along the curve straddle its jumps.  So the list is split in space instead, as a
+    // bounding-volume hierarchy is built: a part goes in two across the axis and at the multiple of 32 spheres where
+    // area(left box) * spheres left + area(right box) * spheres right is smallest (a box is met by rays in
+    // proportion to its area), until a part is one tile; within a tile the spheres stay along the curve (the compare
+    // tree's groups hold neighbours).  A sphere far larger or farther out than the rest (the filter leaves those to a
+    // test of their own) counts as the point of its clamped cell.
+    std::vector<double> ext(n);
+    for (int i = 0; i < n; i++)
+        ext[i] = std::sqrt(coord(i, 0) * coord(i, 0) + coord(i, 1) * coord(i, 1) + coord(i, 2) * coord(i, 2)) + std::fabs((double)spheres[i].radius);
+    std::vector<double> by_size(ext);
+    std::sort(by_size.begin(), by_size.end());          // NaN extents: any order will do, they compare false below
+    const double outlier_from = 4.0 * by_size[n / 2];
+    std::vector<double> blo((size_t)n * 3), bhi((size_t)n * 3);
+    for (int i = 0; i < n; i++) {
+        const bool plain = ext[i] <= outlier_from;
+        const double r = plain ? std::fabs((double)spheres[i].radius) : 0.0;
+        for (int a = 0; a < 3; a++) {
+            const double c = plain ? coord(i, a) : lo[a] + ((double)cell[(size_t)i * 3 + a] + 0.5) * span / cells;
+            blo[(size_t)i * 3 + a] = c - r;
+            bhi[(size_t)i * 3 + a] = c + r;
+        }
+    }
+    struct Box {
+        double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
+        void add(const double *bl, const double *bh) { for (int a = 0; a < 3; a++) { l[a] = std::min(l[a], bl[a]); h[a] = std::max(h[a], bh[a]); } }
+        double area() const {
+            const double x = h[0] - l[0], y = h[1] - l[1], z = h[2] - l[2];
+            return x < 0.0 ? 0.0 : x * y + y * z + z * x;
+        }
+    };
+    std::vector<int32_t> trial;
+    std::vector<double> left_area;
+    std::function<void(int, int)> split = [&](int begin, int end) {
+        const int m = end - begin, tiles = (m + kTileSpheres - 1) / kTileSpheres;
+        if (tiles <= 1) return;
+        double best_cost = std::numeric_limits<double>::infinity();
+        int best_left = 0, best_axis = 0;
+        for (int axis = 0; axis < 3; axis++) {
+            // [begin, end) is in curve order on entry: the stable sort keeps it within equal coordinates, so the
+            // order depends on nothing but the scene
+            trial.assign(order.begin() + begin, order.begin() + end);
+            std::stable_sort(trial.begin(), trial.end(), [&](int32_t a, int32_t b) {
+                return blo[(size_t)a * 3 + axis] + bhi[(size_t)a * 3 + axis] < blo[(size_t)b * 3 + axis] + bhi[(size_t)b * 3 + axis];
+            });
+            left_area.assign(tiles, 0.0);
+            Box box;
+            for (int k = 0; k < m; k++) {
+                if (k % kTileSpheres == 0) left_area[k / kTileSpheres] = box.area();
+                box.add(&blo[(size_t)trial[k] * 3], &bhi[(size_t)trial[k] * 3]);
+            }
+            box = Box();
+            for (int k = m - 1; k >= kTileSpheres; k--) {
+                box.add(&blo[(size_t)trial[k] * 3], &bhi[(size_t)trial[k] * 3]);
+                if (k % kTileSpheres != 0) continue;
+                const double cost = left_area[k / kTileSpheres] * (double)k + box.area() * (double)(m - k);
+                // (a part of more than eight tiles is cut in its middle half: the depth, and with it the time, stay bounded)
+                if (tiles > 8 && (k < m / 4 || k > m - m / 4)) continue;
+                if (cost < best_cost) { best_cost = cost; best_left = k; best_axis = axis; }
+            }
+        }
+        if (best_left == 0) return;                      // nothing finite to go by: the part stays along the curve
+        std::stable_sort(order.begin() + begin, order.begin() + end, [&](int32_t a, int32_t b) {
+            return blo[(size_t)a * 3 + best_axis] + bhi[(size_t)a * 3 + best_axis] < blo[(size_t)b * 3 + best_axis] + bhi[(size_t)b * 3 + best_axis];
+        });
+        const int mid = begin + best_left;
+        std::stable_sort(order.begin() + begin, order.begin() + mid, along_curve);
+        std::stable_sort(order.begin() + mid, order.begin() + end, along_curve);
+        split(begin, mid);
+        split(mid, end);
+    };
+    split(0, n);
     return order;
 }
 

@@ -17,7 +17,10 @@ if scene.startswith("gen"):        # genN: rt_scene_generate with half extent N
 else:
     sph = np.fromfile(os.path.join(ROOT, "tests", "golden", "scene_%s.bin" % scene), dtype=rt.SPHERE_DTYPE)
 rt.init(0)
+import time
+t0 = time.perf_counter()
 rt.set_world(sph)
+print("set_world %d spheres: %.1f ms" % (len(sph), (time.perf_counter() - t0) * 1e3), flush=True)
 h = rt.height_for(w)
 cam = rt.camera(w, h)
 buf = np.zeros((h, w, 4), np.uint8)
@@ -25,5 +28,6 @@ for r in range(reps):
     st = rt.render(cam, w, h, spp, 50, build=build, chunk_spp=chunk, out=buf)['stats']
     print("%s n=%d %dx%d spp %d: kernel %.2f ms  %.1f Msamples/s  frac %.4f  rays/sample %.3f" % (
         build_name, len(sph), w, h, spp, st.kernel_ms, st.samples / st.kernel_ms / 1e3,
-        18.0 * st.sphere_tests / (st.kernel_ms * 1e-3) / 157.3e12, st.rays / st.samples), flush=True)
+        18.0 * st.sphere_tests / (st.kernel_ms * 1e-3) / 157.3e12, st.rays / st.samples) +
+          ("  tiles/scan %.2f" % (st.tile_products / st.wave_scans) if st.wave_scans else ""), flush=True)
 rt.shutdown()
