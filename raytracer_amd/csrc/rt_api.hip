@@ -1094,27 +1094,26 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
             tbounds[(size_t)t * 5 + part] = make_float4((float)c[0], (float)c[1], (float)c[2], (float)(rad * 1.0001));
         }
     }
-    // Axis-aligned boxes of the tiles' filtered spheres as {centre, half extents}: the matrix scan multiplies a tile only if
+    // Axis-aligned boxes of the tiles' filtered spheres as centre and half extents: the matrix scan multiplies a tile only if
     // the box meets a live ray of the wave (rt_trace_impl.h).  Rounded outwards; a tile without filtered spheres gets a
-    // box nothing meets.
-    std::vector<float4> tboxes((size_t)std::max(1, ntiles) * 2, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-    for (int t = 0; t < ntiles; t++) {
+    // box nothing meets.  Two tiles share a record of 12 floats, {cx, cx', cy, cy'}, {cz, cz', hx, hx'}, {hy, hy', hz, hz'}:
+    // the test runs on two tiles per packed-FP32 instruction.
+    const int npairs = (std::max(1, ntiles) + 1) / 2;
+    std::vector<float> tboxes((size_t)npairs * 12, 0.0f);
+    for (int t = 0; t < npairs * 2; t++) {
+        float *rec = &tboxes[(size_t)(t / 2) * 12 + (t & 1)];
+        const float ninf = -std::numeric_limits<float>::infinity();
+        rec[6] = rec[8] = rec[10] = ninf;
+        if (t >= ntiles) continue;
         const float4 lo = tbounds[(size_t)t * 5 + 3], hi = tbounds[(size_t)t * 5 + 4];
-        if (!(lo.w > 0.0f)) {
-            const float ninf = -std::numeric_limits<float>::infinity();
-            tboxes[(size_t)t * 2 + 1] = make_float4(ninf, ninf, ninf, 0.0f);
-            continue;
-        }
-        const double c[3] = {0.5 * ((double)lo.x + hi.x), 0.5 * ((double)lo.y + hi.y), 0.5 * ((double)lo.z + hi.z)};
-        const float cf[3] = {(float)c[0], (float)c[1], (float)c[2]};
-        float hf[3];
+        if (!(lo.w > 0.0f)) continue;
         const double l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
         for (int a = 0; a < 3; a++) {
-            const double half = std::max(h[a] - (double)cf[a], (double)cf[a] - l[a]);      // about the rounded centre
-            hf[a] = std::nextafter((float)half, std::numeric_limits<float>::infinity());
+            const float cf = (float)(0.5 * (l[a] + h[a]));
+            const double half = std::max(h[a] - (double)cf, (double)cf - l[a]);      // about the rounded centre
+            rec[2 * a] = cf;
+            rec[6 + 2 * a] = std::nextafter((float)half, std::numeric_limits<float>::infinity());
         }
-        tboxes[(size_t)t * 2] = make_float4(cf[0], cf[1], cf[2], 0.0f);
-        tboxes[(size_t)t * 2 + 1] = make_float4(hf[0], hf[1], hf[2], 0.0f);
     }
     for (int k = 0; k < g_nctx; k++) { g_ctx[k].n_pad = 0; g_ctx[k].n = 0; }
     for (int k = 0; k < g_nctx; k++) {
@@ -1127,8 +1126,8 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
             HIP_TRY(g.aimg.reserve(aimg.size() * sizeof(uint16_t)));
             HIP_TRY(hipMemcpy(g.aimg.p, aimg.data(), aimg.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         }
-        HIP_TRY(g.tboxes.reserve(tboxes.size() * sizeof(float4)));
-        HIP_TRY(hipMemcpy(g.tboxes.p, tboxes.data(), tboxes.size() * sizeof(float4), hipMemcpyHostToDevice));
+        HIP_TRY(g.tboxes.reserve(tboxes.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(g.tboxes.p, tboxes.data(), tboxes.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(g.tbounds.reserve(tbounds.size() * sizeof(float4)));
         HIP_TRY(hipMemcpy(g.tbounds.p, tbounds.data(), tbounds.size() * sizeof(float4), hipMemcpyHostToDevice));
         HIP_TRY(g.pairs.reserve(pairs.size() * sizeof(float)));

@@ -73,7 +73,7 @@ static_assert(kMatWaveBytes % 16 == 0, "the wave regions stay 16-byte aligned");
 // [caller's index 2 B per sphere][tile boxes 32 B per tile][wave regions]
 inline size_t matrix_lds_bytes(int n_pad, int ntiles)
 {
-    return (size_t)ntiles * 128 * 16 + (size_t)n_pad * 16 + (size_t)n_pad * 2 + (size_t)ntiles * 32 + (size_t)(kMatBlockThreads / 64) * kMatWaveBytes;
+    return (size_t)ntiles * 128 * 16 + (size_t)n_pad * 16 + (size_t)n_pad * 2 + (size_t)((ntiles + 1) / 2) * 48 + (size_t)(kMatBlockThreads / 64) * kMatWaveBytes;
 }
 constexpr int kMaxTilesMatrix = 32;        // what fits beside the wave regions of 16 waves (the host checks matrix_lds_bytes)
 constexpr int kMaxSpheresMatrix = kMaxTilesMatrix * kTileSpheres;
@@ -96,7 +96,7 @@ struct TraceParams {
     const uint4 *aimg;                     // [ntiles][2][64] f16 fragments of the matrix scan, or nullptr
     const float4 *tile_bounds;             // [ntiles][5] bounding spheres {centre, radius} of a tile's filtered spheres and of its two
                                            // 16-sphere halves (radius < 0: empty); read by the diagnostic build only
-    const float4 *tile_boxes;              // [ntiles][2] axis-aligned box {centre, half extents} of a tile's filtered spheres (the matrix scan
+    const float4 *tile_boxes;              // [pairs of tiles][3] axis-aligned boxes of the tiles' filtered spheres, centres and half extents of two tiles interleaved (the matrix scan
                                            // skips the tiles whose box no live ray of the wave meets), or nullptr
     float box_margin;                      // by how much a ray widens every box, per unit of |O| + max |C|
     float mat_scale;                       // power-of-two scale of the matrix scan's frame

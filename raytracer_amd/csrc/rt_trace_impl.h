@@ -737,25 +737,40 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
         const float oix = q.ox * ix, oiy = q.oy * iy, oiz = q.oz * iz;
         const float wo = fmaf(q.oz, q.oz, fmaf(q.oy, q.oy, q.ox * q.ox));
         const float widen = fmaf(__builtin_amdgcn_sqrtf(wo), 1.0000005f, p.c_near) * p.box_margin;          // 2^-9 (|O| + max |C|)
-        auto meets = [&](int t) {                          // lanes whose ray meets the box of tile t
-            const float4 bc = s_box[2 * t], bh = s_box[2 * t + 1];
-            const float hx = bh.x + widen, hy = bh.y + widen, hz = bh.z + widen;
-            const float mx = __builtin_fmaf(bc.x, ix, -oix), my = __builtin_fmaf(bc.y, iy, -oiy), mz = __builtin_fmaf(bc.z, iz, -oiz);
-            const float nx = __builtin_fmaf(-hx, fabsf(ix), mx), ny = __builtin_fmaf(-hy, fabsf(iy), my), nz = __builtin_fmaf(-hz, fabsf(iz), mz);
-            const float fx = __builtin_fmaf(hx, fabsf(ix), mx), fy = __builtin_fmaf(hy, fabsf(iy), my), fz = __builtin_fmaf(hz, fabsf(iz), mz);
-            const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx, ny), nz), 0.0f);
-            const float t_out = __builtin_fminf(__builtin_fminf(__builtin_fminf(fx, fy), fz), q.closest);
-            return __ballot(!(t_out < t_in)) & live_lanes;
+        // Two tiles per packed-FP32 instruction: the boxes come as {cx, cx', cy, cy'}, {cz, cz', hx, hx'}, {hy, hy', hz, hz'} per
+        // pair of tiles (an odd last tile is paired with a box nothing meets).
+        const f2 ix2 = {ix, ix}, iy2 = {iy, iy}, iz2 = {iz, iz}, oix2 = {oix, oix}, oiy2 = {oiy, oiy}, oiz2 = {oiz, oiz};
+        const f2 ax2 = {fabsf(ix), fabsf(ix)}, ay2 = {fabsf(iy), fabsf(iy)}, az2 = {fabsf(iz), fabsf(iz)}, widen2 = {widen, widen};
+        auto meets2 = [&](int pr, unsigned long long &first, unsigned long long &second) {    // lanes whose ray meets the boxes of tiles 2 pr, 2 pr + 1
+            const float4 ba = s_box[3 * pr], bb = s_box[3 * pr + 1], bc = s_box[3 * pr + 2];
+            const f2 cx = {ba.x, ba.y}, cy = {ba.z, ba.w}, cz = {bb.x, bb.y};
+            const f2 hx = f2{bb.z, bb.w} + widen2, hy = f2{bc.x, bc.y} + widen2, hz = f2{bc.z, bc.w} + widen2;
+            const f2 mx = __builtin_elementwise_fma(cx, ix2, -oix2), my = __builtin_elementwise_fma(cy, iy2, -oiy2), mz = __builtin_elementwise_fma(cz, iz2, -oiz2);
+            const f2 nx = __builtin_elementwise_fma(-hx, ax2, mx), ny = __builtin_elementwise_fma(-hy, ay2, my), nz = __builtin_elementwise_fma(-hz, az2, mz);
+            const f2 fx = __builtin_elementwise_fma(hx, ax2, mx), fy = __builtin_elementwise_fma(hy, ay2, my), fz = __builtin_elementwise_fma(hz, az2, mz);
+            const float in0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx.x, ny.x), nz.x), 0.0f);
+            const float out0 = __builtin_fminf(__builtin_fminf(__builtin_fminf(fx.x, fy.x), fz.x), q.closest);
+            const float in1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx.y, ny.y), nz.y), 0.0f);
+            const float out1 = __builtin_fminf(__builtin_fminf(__builtin_fminf(fx.y, fy.y), fz.y), q.closest);
+            first = __ballot(!(out0 < in0)) & live_lanes;
+            second = __ballot(!(out1 < in1)) & live_lanes;
         };
-        // from the last tile of the group to the first, the mask shifted up by one per tile; four tiles per step, so that
+        // from the last pair of the group to the first, the mask shifted up by two per pair; two pairs per step, so that
         // their box reads are in flight together
         unsigned long long need = 0ULL;
-        int k = group;
-        for (; k >= 4; k -= 4) {
-            const unsigned long long m3 = meets(t0 + k - 1), m2 = meets(t0 + k - 2), m1 = meets(t0 + k - 3), m0 = meets(t0 + k - 4);
+        int k = (group + 1) >> 1;
+        const int p0 = t0 >> 1;
+        for (; k >= 2; k -= 2) {
+            unsigned long long m3, m2, m1, m0;
+            meets2(p0 + k - 1, m2, m3);
+            meets2(p0 + k - 2, m0, m1);
             need = (need << 4) | (m3 != 0ULL ? 8ULL : 0ULL) | (m2 != 0ULL ? 4ULL : 0ULL) | (m1 != 0ULL ? 2ULL : 0ULL) | (m0 != 0ULL ? 1ULL : 0ULL);
         }
-        for (; k >= 1; k--) need = (need << 1) | (meets(t0 + k - 1) != 0ULL ? 1ULL : 0ULL);
+        if (k >= 1) {
+            unsigned long long m1, m0;
+            meets2(p0, m0, m1);
+            need = (need << 2) | (m1 != 0ULL ? 2ULL : 0ULL) | (m0 != 0ULL ? 1ULL : 0ULL);
+        }
         return need;
     };
     const unsigned long long need_first = tiles_in_need(0);
@@ -1219,13 +1234,14 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
         for (int i = threadIdx.x; i < p.n_pad; i += blockDim.x) gm[i] = p.geom[i];
         uint16_t *o16 = reinterpret_cast<uint16_t *>(gm + p.n_pad);        // [n_pad] caller's indices (below 65536 here)
         for (int i = threadIdx.x; i < p.n_pad; i += blockDim.x) o16[i] = (uint16_t)p.orig[i];
-        float4 *bx = reinterpret_cast<float4 *>(o16 + p.n_pad);            // [ntiles][2] tile boxes (n_pad is a multiple of 8: 16-byte aligned)
+        float4 *bx = reinterpret_cast<float4 *>(o16 + p.n_pad);            // [pairs of tiles][3] tile boxes (n_pad is a multiple of 8: 16-byte aligned)
+        const int nbox = ((p.ntiles + 1) >> 1) * 3;
         if (p.tile_boxes != nullptr)
-            for (int i = threadIdx.x; i < p.ntiles * 2; i += blockDim.x) bx[i] = p.tile_boxes[i];
+            for (int i = threadIdx.x; i < nbox; i += blockDim.x) bx[i] = p.tile_boxes[i];
         s_aimg = img; s_geom = gm; s_orig16 = o16;
         s_box = p.tile_boxes != nullptr ? bx : nullptr;
         s_matA = p.matA; s_matB = p.matB;
-        pool = reinterpret_cast<char *>(bx + p.ntiles * 2) + (threadIdx.x >> 6) * kMatWaveBytes;
+        pool = reinterpret_cast<char *>(bx + nbox) + (threadIdx.x >> 6) * kMatWaveBytes;
         queue = nullptr;
     } else if (VARIANT == kScanMatrixGlobal) {
         s_aimg = p.aimg; s_geom = p.geom; s_matA = p.matA; s_matB = p.matB;
