@@ -257,6 +257,14 @@ uint32_t rt_height_for(uint32_t width, float aspect_ratio);
  * small.  Pure host code. */
 int rt_scene_generate(int half_extent, uint32_t lcg_seed, rt_sphere *out, size_t cap, size_t *count);
 
+/* The order rt_set_world gives the spheres on the device (no counterpart in the reference, whose hit() walks the
+ * caller's list, Main.c:688-713; nothing a caller sees depends on the order).  order_out[k] = index in `spheres` of the
+ * k-th sphere in device order, `count` entries.  Spheres 32 t .. 32 t + 31 in device order are tile t of the matrix scan,
+ * which skips a tile whose axis-aligned bounding box no ray of a wave meets: split_tiles != 0 gives the order
+ * rt_set_world uses (the list split in space until a part is one tile), 0 the plain Z-order curve it is compared with
+ * (RTMI_ORDER=curve in the environment at rt_init).  For tests and scene tools.  Pure host code. */
+int rt_world_layout(const rt_sphere *spheres, size_t count, int split_tiles, int32_t *order_out);
+
 /* Optional: page-locked host memory for a framebuffer the caller keeps for many frames (in place
  * of the arena block of Main.c:998, which is also the texture upload source of render_to_screen,
  * Main.c:935): rt_render's read-back of a whole frame into it is one DMA transfer instead of a

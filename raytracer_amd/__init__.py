@@ -64,7 +64,7 @@ assert SPHERE_DTYPE.itemsize == 40
 
 EXPORTS = ["rt_init", "rt_init_devices", "rt_set_world", "rt_render", "rt_render_device", "rt_render_device_noalloc",
            "rt_render_progressive", "rt_part_rows", "rt_part_row_at", "rt_chunk_for", "rt_camera_setup", "rt_camera_defaults", "rt_height_for",
-           "rt_scene_generate", "rt_host_alloc", "rt_host_free", "rt_shutdown", "rt_last_error"]
+           "rt_scene_generate", "rt_world_layout", "rt_host_alloc", "rt_host_free", "rt_shutdown", "rt_last_error"]
 
 _lib = None
 
@@ -109,6 +109,8 @@ def lib():
         L.rt_camera_defaults.argtypes = [C.POINTER(CameraParams)]
         L.rt_height_for.restype = C.c_uint32
         L.rt_height_for.argtypes = [C.c_uint32, C.c_float]
+        L.rt_world_layout.restype = C.c_int
+        L.rt_world_layout.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         L.rt_scene_generate.restype = C.c_int
         L.rt_scene_generate.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.rt_host_alloc.restype = C.c_void_p
@@ -169,6 +171,14 @@ def scene_generate(half_extent=11, lcg_seed=0):
     n = C.c_size_t(0)
     _check(lib().rt_scene_generate(half_extent, lcg_seed, out.ctypes.data, cap, C.byref(n)), "rt_scene_generate")
     return out[:n.value].copy()
+
+
+def world_layout(spheres, split_tiles=True):
+    """rt_world_layout: the device order of the spheres (order[k] = caller's index of the k-th sphere on the device)."""
+    spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
+    order = np.zeros(len(spheres), dtype=np.int32)
+    _check(lib().rt_world_layout(spheres.ctypes.data, len(spheres), 1 if split_tiles else 0, order.ctypes.data), "rt_world_layout")
+    return order
 
 
 def default_params():

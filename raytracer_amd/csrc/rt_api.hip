@@ -542,10 +542,10 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
 #endif
 #ifdef RT_DIAG_STAMPS
             {
-                const double tot = (double)(c[9] + c[10] + c[11] + c[12] + c[13] + c[14] + c[15] + c[20] + c[21]);
-                fprintf(stderr, "diag: wave-cycles per phase (share of the main loop): unit hand-out %.2f %%, new sample %.2f %%, "
+                const double tot = (double)(c[9] + c[10] + c[11] + c[12] + c[13] + c[14] + c[15] + c[20] + c[21] + c[23]);
+                fprintf(stderr, "diag: wave-cycles per phase (share of the main loop): unit hand-out %.2f %%, new sample %.2f %%, tile boxes %.2f %%, "
                         "ray features %.2f %%, tile loop (products, compares) %.2f %%, appends %.2f %%, drain %.2f %%, big spheres %.2f %%, shade %.2f %%, shared-ray search %.2f %%; "
-                        "%.0f cycles per wave scan\n", 100.0 * c[9] / tot, 100.0 * c[10] / tot, 100.0 * c[20] / tot, 100.0 * c[11] / tot, 100.0 * c[21] / tot, 100.0 * c[12] / tot,
+                        "%.0f cycles per wave scan\n", 100.0 * c[9] / tot, 100.0 * c[10] / tot, 100.0 * c[23] / tot, 100.0 * c[20] / tot, 100.0 * c[11] / tot, 100.0 * c[21] / tot, 100.0 * c[12] / tot,
                         100.0 * c[13] / tot, 100.0 * c[14] / tot, 100.0 * c[15] / tot, tot / (double)c[5]);
                 if (c[18] > 0 && c[17] > 0)
                     fprintf(stderr, "diag: %llu waves lived %.1f %% of the longest wave's %.3f M cycles on average "
@@ -825,7 +825,7 @@ static uint32_t morton3(uint32_t x, uint32_t y, uint32_t z)
 // the kernel time; a shuffled list ran 6 % slower than the caller's order, which was sorted by one coordinate).
 // Nothing a caller sees depends on the order: hits are reported by the caller's index and equal distances go to
 // the lower caller's index (order[] travels to the device for that).
-static std::vector<int32_t> device_order(const rt_sphere *spheres, int n)
+static std::vector<int32_t> device_order(const rt_sphere *spheres, int n, bool split_tiles)
 {
     std::vector<int32_t> order(n);
     for (int i = 0; i < n; i++) order[i] = i;
@@ -867,7 +867,7 @@ static std::vector<int32_t> device_order(const rt_sphere *spheres, int n)
     }
     auto along_curve = [&](int32_t a, int32_t b) { return key[a] < key[b]; };
     std::stable_sort(order.begin(), order.end(), along_curve);
-    if (g_curve_order || n <= kTileSpheres) return order;
+    if (!split_tiles || n <= kTileSpheres) return order;
     // Tiles as boxes: the matrix scan skips a tile whose bounding box no ray of the wave meets (rt_trace_impl.h), and
     // 32 consecutive spheres along the curve straddle its jumps.  So the list is split in space instead, as a
     // bounding-volume hierarchy is built: a part goes in two across the axis and at the multiple of 32 spheres where
@@ -956,7 +956,7 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
     const int n = (int)count;
     const int n_pad = n == 0 ? kGeomPad : ((n + kGeomPad - 1) / kGeomPad) * kGeomPad;
     // From here on "sphere i" is the i-th sphere in device order; orig[i] is its index in the caller's list.
-    std::vector<int32_t> orig = g_caller_order ? std::vector<int32_t>() : device_order(caller_spheres, n);
+    std::vector<int32_t> orig = g_caller_order ? std::vector<int32_t>() : device_order(caller_spheres, n, !g_curve_order);
     if (g_caller_order) { orig.resize(n); for (int i = 0; i < n; i++) orig[i] = i; }
     std::vector<rt_sphere> in_order(n > 0 ? n : 1);
     for (int i = 0; i < n; i++) in_order[i] = caller_spheres[orig[i]];
@@ -1155,6 +1155,17 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
     }
     for (int k = 0; k < g_nctx; k++) { g_ctx[k].n = n; g_ctx[k].n_pad = n_pad; }
     return RT_OK;
+}
+
+int rt_world_layout(const rt_sphere *spheres, size_t count, int split_tiles, int32_t *order_out)
+{
+    return guarded("rt_world_layout", [&]() {
+        if ((!spheres || !order_out) && count) return fail(RT_ERR_ARG, "rt_world_layout: null argument");
+        if (count > (size_t)kMaxSpheres) return fail(RT_ERR_ARG, "rt_world_layout: %zu spheres; at most %d are supported", count, kMaxSpheres);
+        const std::vector<int32_t> order = device_order(spheres, (int)count, split_tiles != 0);
+        for (size_t i = 0; i < count; i++) order_out[i] = order[i];
+        return (int)RT_OK;
+    });
 }
 
 int rt_set_world(const rt_sphere *spheres, size_t count)

@@ -436,7 +436,7 @@ __device__ __forceinline__ void exact_test(const float4 *s_geom, int i, Probe &q
 struct Diag {
     uint32_t branches, passes, drain_iters, drain_lanes, scans, scan_lanes, shared_rays, lost_hits, tiles_bound, tiles_halfbound, quads_bound, tiles_box, pairs_box, tiles_run;
     uint32_t scans_by_live[4];      // wave scans with at most 8 / 16 / 32 / 48 live rays
-    unsigned long long t_handout, t_regen, t_hit, t_drain, t_big, t_shade, t_shared, t_feat, t_append;
+    unsigned long long t_handout, t_regen, t_hit, t_drain, t_big, t_shade, t_shared, t_feat, t_append, t_cull;
 };
 #define RT_DIAG_ARG , Diag &dg
 #define RT_DIAG_PASS , dg
@@ -773,7 +773,19 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
         }
         return need;
     };
-    const unsigned long long need_first = tiles_in_need(0);
+#ifdef RT_DIAG_STAMPS
+    const unsigned long long tc0 = RT_STAMP();
+#endif
+    unsigned long long need_first = tiles_in_need(0);
+#ifdef RT_DIAG_STAMPS
+    {                                                             // the box tests stay between their two stamps
+        uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)need_first), hi = __builtin_amdgcn_readfirstlane((uint32_t)(need_first >> 32));
+        asm volatile("" : "+s"(lo), "+s"(hi));
+        need_first = ((unsigned long long)hi << 32) | lo;
+    }
+    const unsigned long long tc1 = RT_STAMP();
+    dg.t_cull += tc1 - tc0;
+#endif
     RT_MARK("features");
     // ray features in the frame scaled by p.mat_scale (a power of two)
     const float ox = q.ox * p.mat_scale, oy = q.oy * p.mat_scale, oz = q.oz * p.mat_scale;
@@ -854,7 +866,11 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
 #pragma unroll
     for (int k = 0; k < 16; k++) asm volatile("" : "+v"(B[k >> 3][(k >> 2) & 1][k & 3]));
 #endif
-    dg.t_feat += RT_STAMP() - tb0 - (dg.t_big - t_big_before);        // ray features and their fragments
+#ifdef RT_DIAG_STAMPS
+    dg.t_feat += RT_STAMP() - tb0 - (dg.t_big - t_big_before) - (tc1 - tc0);        // ray features and their fragments
+#else
+    (void)tb0; (void)t_big_before;
+#endif
 #endif
     RT_MARK("tile_loop_setup");
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1671,7 +1687,8 @@ __global__ __launch_bounds__(is_matrix(VARIANT) ? kMatBlockThreads : kBlockThrea
     if (__lane_id() == 0) {
         atomicAdd(&p.counters[9], dg.t_handout);
         atomicAdd(&p.counters[10], dg.t_regen);
-        atomicAdd(&p.counters[11], dg.t_hit - dg.t_drain - dg.t_big - dg.t_feat - dg.t_append);      // the tile (pair) loop: products and compares
+        atomicAdd(&p.counters[11], dg.t_hit - dg.t_drain - dg.t_big - dg.t_feat - dg.t_append - dg.t_cull);      // the tile loop: products and compares
+        atomicAdd(&p.counters[23], dg.t_cull);
         atomicAdd(&p.counters[20], dg.t_feat);
         atomicAdd(&p.counters[21], dg.t_append);
         atomicAdd(&p.counters[12], dg.t_drain);
