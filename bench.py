@@ -417,7 +417,9 @@ def main():
                     "tiles_multiplied_per_wave_scan": round(float(np.mean([float(s.tile_products) / max(float(s.wave_scans), 1.0) for s in stats])), 3),
                     "tiles_per_scene": int(stats[-1].scan_tiles),
                     "matrix_flop_per_launch": rates["matrix_flop"],
-                    "matrix_flop_per_launch_from_counters": busy.get("mfma_flop_per_launch")}
+                    "matrix_flop_per_launch_from_counters": busy.get("mfma_flop_per_launch"),
+                    # what the kernel waits for since it multiplies a third of the tiles: the vector ALU's issue port
+                    "binding_resource": "vector ALU issue port", "binding_resource_busy": busy.get("valu_issue")}
         else:
             roof = {"bound": "valu_fp32", "resource": "vector ALU (packed-FP32 scan: fewer than 32 spheres)",
                     "achieved": round(rates["algorithmic_tflops"], 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
