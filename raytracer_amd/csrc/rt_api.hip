@@ -421,6 +421,8 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             tp.aimg = (const uint4 *)g.aimg.p; tp.ntiles = g.ntiles;
             tp.tile_bounds = g.ntiles > 0 ? (const float4 *)g.tbounds.p : nullptr;
             tp.tile_boxes = (g.ntiles > 0 && !getenv("RTMI_NO_CULL")) ? (const float4 *)g.tboxes.p : nullptr;      // (RTMI_NO_CULL: comparison runs)
+            tp.group_boxes = tp.tile_boxes != nullptr && !getenv("RTMI_NO_BOX_GROUPS")
+                                 ? tp.tile_boxes + (size_t)((g.ntiles + kBoxGroupTiles - 1) / kBoxGroupTiles) * (kBoxGroupTiles / 2) * 3 : nullptr;
             tp.box_margin = 1.0f / 512.0f;
             tp.mat_scale = g.mat_scale; tp.mat_c_near = g.c_near * g.mat_scale;
             tp.n = g.n; tp.n_pad = g.n_pad;
@@ -1098,22 +1100,40 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
     // the box meets a live ray of the wave (rt_trace_impl.h).  Rounded outwards; a tile without filtered spheres gets a
     // box nothing meets.  Two tiles share a record of 12 floats, {cx, cx', cy, cy'}, {cz, cz', hx, hx'}, {hy, hy', hz, hz'}:
     // the test runs on two tiles per packed-FP32 instruction.
-    const int npairs = (std::max(1, ntiles) + 1) / 2;
-    std::vector<float> tboxes((size_t)npairs * 12, 0.0f);
-    for (int t = 0; t < npairs * 2; t++) {
-        float *rec = &tboxes[(size_t)(t / 2) * 12 + (t & 1)];
+    // Behind the tiles' records (padded to whole groups of eight tiles): the boxes of those groups in the same form, two groups
+    // per record.  The spheres are in the leaf order of a hierarchy (device_order), so eight consecutive tiles are
+    // neighbours too; a scene of more than 64 tiles asks the groups first and the tiles of the groups that are met.
+    const int ngroups = (std::max(1, ntiles) + kBoxGroupTiles - 1) / kBoxGroupTiles;
+    const int npairs = ngroups * (kBoxGroupTiles / 2), ngpairs = (ngroups + 1) / 2;
+    std::vector<float> tboxes((size_t)(npairs + ngpairs) * 12, 0.0f);
+    auto put_box = [&](float *rec, const double *l, const double *h, bool any) {
         const float ninf = -std::numeric_limits<float>::infinity();
         rec[6] = rec[8] = rec[10] = ninf;
-        if (t >= ntiles) continue;
-        const float4 lo = tbounds[(size_t)t * 5 + 3], hi = tbounds[(size_t)t * 5 + 4];
-        if (!(lo.w > 0.0f)) continue;
-        const double l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
+        if (!any) return;
         for (int a = 0; a < 3; a++) {
             const float cf = (float)(0.5 * (l[a] + h[a]));
             const double half = std::max(h[a] - (double)cf, (double)cf - l[a]);      // about the rounded centre
             rec[2 * a] = cf;
             rec[6 + 2 * a] = std::nextafter((float)half, std::numeric_limits<float>::infinity());
         }
+    };
+    for (int t = 0; t < npairs * 2; t++) {
+        const bool any = t < ntiles && tbounds[(size_t)t * 5 + 3].w > 0.0f;
+        const float4 lo = any ? tbounds[(size_t)t * 5 + 3] : make_float4(0, 0, 0, 0), hi = any ? tbounds[(size_t)t * 5 + 4] : make_float4(0, 0, 0, 0);
+        const double l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
+        put_box(&tboxes[(size_t)(t / 2) * 12 + (t & 1)], l, h, any);
+    }
+    for (int gidx = 0; gidx < ngpairs * 2; gidx++) {
+        double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
+        bool any = false;
+        for (int t = gidx * kBoxGroupTiles; t < std::min(ntiles, (gidx + 1) * kBoxGroupTiles); t++) {
+            const float4 lo = tbounds[(size_t)t * 5 + 3], hi = tbounds[(size_t)t * 5 + 4];
+            if (!(lo.w > 0.0f)) continue;
+            any = true;
+            const double tl[3] = {lo.x, lo.y, lo.z}, th[3] = {hi.x, hi.y, hi.z};
+            for (int a = 0; a < 3; a++) { l[a] = std::min(l[a], tl[a]); h[a] = std::max(h[a], th[a]); }
+        }
+        put_box(&tboxes[(size_t)(npairs + gidx / 2) * 12 + (gidx & 1)], l, h, any);
     }
     for (int k = 0; k < g_nctx; k++) { g_ctx[k].n_pad = 0; g_ctx[k].n = 0; }
     for (int k = 0; k < g_nctx; k++) {

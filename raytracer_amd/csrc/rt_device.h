@@ -58,6 +58,7 @@ constexpr int queue_lds_bytes(int block_threads, int slots) { return (block_thre
 enum { kScanVectorLds = 0, kScanVectorGlobal = 1, kScanMatrix = 2, kScanMatrixGlobal = 3, kScanVariants = 4 };
 constexpr bool is_matrix(int variant) { return variant == kScanMatrix || variant == kScanMatrixGlobal; }
 constexpr int kTileSpheres = 32;
+constexpr int kBoxGroupTiles = 8;                  // tiles per group of the box hierarchy of large scenes (64 tiles, one mask, are eight groups)
 constexpr int kMaxSpheresMatrixGlobal = 65504;   // a candidate entry and a result key hold sphere indices in 16 bits
 constexpr int kMinSpheresMatrix = 32;      // smaller scenes: the vector scan (measured break-even 20-40 spheres)
 constexpr int kMatBlockThreads = RT_MAT_THREADS;   // one workgroup per CU: 4 waves per SIMD at 128 VGPRs
@@ -98,6 +99,8 @@ struct TraceParams {
                                            // 16-sphere halves (radius < 0: empty); read by the diagnostic build only
     const float4 *tile_boxes;              // [pairs of tiles][3] axis-aligned boxes of the tiles' filtered spheres, centres and half extents of two tiles interleaved (the matrix scan
                                            // skips the tiles whose box no live ray of the wave meets), or nullptr
+    const float4 *group_boxes;             // [pairs of groups of kBoxGroupTiles tiles][3] the same for groups of consecutive tiles (scenes of more than 64 tiles ask
+                                           // them first), or nullptr: every tile is asked
     float box_margin;                      // by how much a ray widens every box, per unit of |O| + max |C|
     float mat_scale;                       // power-of-two scale of the matrix scan's frame
     float mat_c_near;                      // max |C| over the filtered spheres, in that frame

@@ -741,8 +741,8 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
         // pair of tiles (an odd last tile is paired with a box nothing meets).
         const f2 ix2 = {ix, ix}, iy2 = {iy, iy}, iz2 = {iz, iz}, oix2 = {oix, oix}, oiy2 = {oiy, oiy}, oiz2 = {oiz, oiz};
         const f2 ax2 = {fabsf(ix), fabsf(ix)}, ay2 = {fabsf(iy), fabsf(iy)}, az2 = {fabsf(iz), fabsf(iz)}, widen2 = {widen, widen};
-        auto meets2 = [&](int pr, unsigned long long &first, unsigned long long &second) {    // lanes whose ray meets the boxes of tiles 2 pr, 2 pr + 1
-            const float4 ba = s_box[3 * pr], bb = s_box[3 * pr + 1], bc = s_box[3 * pr + 2];
+        auto meets2 = [&](const float4 *boxes, int pr, unsigned long long &first, unsigned long long &second) {    // lanes whose ray meets boxes 2 pr, 2 pr + 1
+            const float4 ba = boxes[3 * pr], bb = boxes[3 * pr + 1], bc = boxes[3 * pr + 2];
             const f2 cx = {ba.x, ba.y}, cy = {ba.z, ba.w}, cz = {bb.x, bb.y};
             const f2 hx = f2{bb.z, bb.w} + widen2, hy = f2{bc.x, bc.y} + widen2, hz = f2{bc.z, bc.w} + widen2;
             const f2 mx = __builtin_elementwise_fma(cx, ix2, -oix2), my = __builtin_elementwise_fma(cy, iy2, -oiy2), mz = __builtin_elementwise_fma(cz, iz2, -oiz2);
@@ -758,17 +758,42 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
         // from the last pair of the group to the first, the mask shifted up by two per pair; two pairs per step, so that
         // their box reads are in flight together
         unsigned long long need = 0ULL;
-        int k = (group + 1) >> 1;
         const int p0 = t0 >> 1;
+        if (!ONE_GROUP && p.group_boxes != nullptr) {
+            // A large scene: the boxes of the (at most eight) groups of eight consecutive tiles first, then the tiles of the
+            // groups some ray meets.  The host pads the tiles' records to whole groups with boxes nothing meets.
+            const int groups = (group + kBoxGroupTiles - 1) / kBoxGroupTiles, g0 = t0 / kBoxGroupTiles;
+            uint32_t met = 0U;
+            for (int k = (groups + 1) >> 1; k >= 1; k--) {
+                unsigned long long m1, m0;
+                meets2(p.group_boxes, (g0 >> 1) + k - 1, m0, m1);
+                met = (met << 2) | (m1 != 0ULL ? 2U : 0U) | (m0 != 0ULL ? 1U : 0U);
+            }
+            while (met != 0U) {
+                const int gi = __builtin_ctz(met);
+                met &= met - 1U;
+                unsigned long long m7, m6, m5, m4, m3, m2, m1, m0;
+                const int pr = p0 + gi * (kBoxGroupTiles / 2);
+                meets2(s_box, pr + 3, m6, m7);
+                meets2(s_box, pr + 2, m4, m5);
+                meets2(s_box, pr + 1, m2, m3);
+                meets2(s_box, pr, m0, m1);
+                const unsigned long long bits = (m7 != 0ULL ? 128ULL : 0ULL) | (m6 != 0ULL ? 64ULL : 0ULL) | (m5 != 0ULL ? 32ULL : 0ULL) | (m4 != 0ULL ? 16ULL : 0ULL) |
+                                                (m3 != 0ULL ? 8ULL : 0ULL) | (m2 != 0ULL ? 4ULL : 0ULL) | (m1 != 0ULL ? 2ULL : 0ULL) | (m0 != 0ULL ? 1ULL : 0ULL);
+                need |= bits << (gi * kBoxGroupTiles);
+            }
+            return need;
+        }
+        int k = (group + 1) >> 1;
         for (; k >= 2; k -= 2) {
             unsigned long long m3, m2, m1, m0;
-            meets2(p0 + k - 1, m2, m3);
-            meets2(p0 + k - 2, m0, m1);
+            meets2(s_box, p0 + k - 1, m2, m3);
+            meets2(s_box, p0 + k - 2, m0, m1);
             need = (need << 4) | (m3 != 0ULL ? 8ULL : 0ULL) | (m2 != 0ULL ? 4ULL : 0ULL) | (m1 != 0ULL ? 2ULL : 0ULL) | (m0 != 0ULL ? 1ULL : 0ULL);
         }
         if (k >= 1) {
             unsigned long long m1, m0;
-            meets2(p0, m0, m1);
+            meets2(s_box, p0, m0, m1);
             need = (need << 2) | (m1 != 0ULL ? 2ULL : 0ULL) | (m0 != 0ULL ? 1ULL : 0ULL);
         }
         return need;
