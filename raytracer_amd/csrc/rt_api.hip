@@ -421,8 +421,12 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             tp.aimg = (const uint4 *)g.aimg.p; tp.ntiles = g.ntiles;
             tp.tile_bounds = g.ntiles > 0 ? (const float4 *)g.tbounds.p : nullptr;
             tp.tile_boxes = (g.ntiles > 0 && !getenv("RTMI_NO_CULL")) ? (const float4 *)g.tboxes.p : nullptr;      // (RTMI_NO_CULL: comparison runs)
-            tp.group_boxes = tp.tile_boxes != nullptr && !getenv("RTMI_NO_BOX_GROUPS")
-                                 ? tp.tile_boxes + (size_t)((g.ntiles + kBoxGroupTiles - 1) / kBoxGroupTiles) * (kBoxGroupTiles / 2) * 3 : nullptr;
+            {
+                const size_t ngroups = (size_t)(g.ntiles + kBoxGroupTiles - 1) / kBoxGroupTiles;
+                const bool groups = tp.tile_boxes != nullptr && !getenv("RTMI_NO_BOX_GROUPS");
+                tp.group_boxes = groups ? tp.tile_boxes + ngroups * (kBoxGroupTiles / 2) * 3 : nullptr;
+                tp.mask_group_boxes = groups ? tp.group_boxes + ((ngroups + 1) / 2) * 3 : nullptr;
+            }
             tp.box_margin = 1.0f / 512.0f;
             tp.mat_scale = g.mat_scale; tp.mat_c_near = g.c_near * g.mat_scale;
             tp.n = g.n; tp.n_pad = g.n_pad;
@@ -1104,8 +1108,8 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
     // per record.  The spheres are in the leaf order of a hierarchy (device_order), so eight consecutive tiles are
     // neighbours too; a scene of more than 64 tiles asks the groups first and the tiles of the groups that are met.
     const int ngroups = (std::max(1, ntiles) + kBoxGroupTiles - 1) / kBoxGroupTiles;
-    const int npairs = ngroups * (kBoxGroupTiles / 2), ngpairs = (ngroups + 1) / 2;
-    std::vector<float> tboxes((size_t)(npairs + ngpairs) * 12, 0.0f);
+    const int npairs = ngroups * (kBoxGroupTiles / 2), ngpairs = (ngroups + 1) / 2, nmpairs = ((std::max(1, ntiles) + 63) / 64 + 1) / 2;
+    std::vector<float> tboxes((size_t)(npairs + ngpairs + nmpairs) * 12, 0.0f);
     auto put_box = [&](float *rec, const double *l, const double *h, bool any) {
         const float ninf = -std::numeric_limits<float>::infinity();
         rec[6] = rec[8] = rec[10] = ninf;
@@ -1123,18 +1127,22 @@ static int set_world_impl(const rt_sphere *caller_spheres, size_t count)
         const double l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
         put_box(&tboxes[(size_t)(t / 2) * 12 + (t & 1)], l, h, any);
     }
-    for (int gidx = 0; gidx < ngpairs * 2; gidx++) {
-        double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
-        bool any = false;
-        for (int t = gidx * kBoxGroupTiles; t < std::min(ntiles, (gidx + 1) * kBoxGroupTiles); t++) {
-            const float4 lo = tbounds[(size_t)t * 5 + 3], hi = tbounds[(size_t)t * 5 + 4];
-            if (!(lo.w > 0.0f)) continue;
-            any = true;
-            const double tl[3] = {lo.x, lo.y, lo.z}, th[3] = {hi.x, hi.y, hi.z};
-            for (int a = 0; a < 3; a++) { l[a] = std::min(l[a], tl[a]); h[a] = std::max(h[a], th[a]); }
+    auto put_groups = [&](int first_record, int records, int tiles_per_group) {          // and behind those, the groups of 64 that share a mask
+        for (int gidx = 0; gidx < records * 2; gidx++) {
+            double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
+            bool any = false;
+            for (int t = gidx * tiles_per_group; t < std::min(ntiles, (gidx + 1) * tiles_per_group); t++) {
+                const float4 lo = tbounds[(size_t)t * 5 + 3], hi = tbounds[(size_t)t * 5 + 4];
+                if (!(lo.w > 0.0f)) continue;
+                any = true;
+                const double tl[3] = {lo.x, lo.y, lo.z}, th[3] = {hi.x, hi.y, hi.z};
+                for (int a = 0; a < 3; a++) { l[a] = std::min(l[a], tl[a]); h[a] = std::max(h[a], th[a]); }
+            }
+            put_box(&tboxes[(size_t)(first_record + gidx / 2) * 12 + (gidx & 1)], l, h, any);
         }
-        put_box(&tboxes[(size_t)(npairs + gidx / 2) * 12 + (gidx & 1)], l, h, any);
-    }
+    };
+    put_groups(npairs, ngpairs, kBoxGroupTiles);
+    put_groups(npairs + ngpairs, nmpairs, 64);
     for (int k = 0; k < g_nctx; k++) { g_ctx[k].n_pad = 0; g_ctx[k].n = 0; }
     for (int k = 0; k < g_nctx; k++) {
         Ctx &g = g_ctx[k];

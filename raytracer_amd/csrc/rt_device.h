@@ -101,6 +101,7 @@ struct TraceParams {
                                            // skips the tiles whose box no live ray of the wave meets), or nullptr
     const float4 *group_boxes;             // [pairs of groups of kBoxGroupTiles tiles][3] the same for groups of consecutive tiles (scenes of more than 64 tiles ask
                                            // them first), or nullptr: every tile is asked
+    const float4 *mask_group_boxes;        // [pairs of groups of 64 tiles][3] and for the groups of 64 tiles that share a mask, or nullptr
     float box_margin;                      // by how much a ray widens every box, per unit of |O| + max |C|
     float mat_scale;                       // power-of-two scale of the matrix scan's frame
     float mat_c_near;                      // max |C| over the filtered spheres, in that frame

@@ -729,9 +729,9 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
     const bool cull = s_box != nullptr;
 #endif
     const unsigned long long live_lanes = __ballot(live);
-    auto tiles_in_need = [&](int t0) {
-        const int group = p.ntiles - t0 < 64 ? p.ntiles - t0 : 64;
-        if (!cull) return group == 64 ? ~0ULL : (1ULL << group) - 1ULL;
+    // body(meets2) with meets2(boxes, pr, first, second) = the lanes whose ray meets boxes 2 pr and 2 pr + 1.  The ray's side of the
+    // test is computed anew per call: kept in registers across the tile loop it would cost more than it does to redo.
+    auto box_tests = [&](auto &&body) {
         // the ray in the form the slab test wants: t of the plane x = c is c * (1 / dx) - ox * (1 / dx)
         const float ix = __builtin_amdgcn_rcpf(q.dx), iy = __builtin_amdgcn_rcpf(q.dy), iz = __builtin_amdgcn_rcpf(q.dz);
         const float oix = q.ox * ix, oiy = q.oy * iy, oiz = q.oz * iz;
@@ -755,6 +755,12 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
             first = __ballot(!(out0 < in0)) & live_lanes;
             second = __ballot(!(out1 < in1)) & live_lanes;
         };
+        return body(meets2);
+    };
+    auto tiles_in_need = [&](int t0) {                     // of tiles t0 .. t0 + 63
+        const int group = p.ntiles - t0 < 64 ? p.ntiles - t0 : 64;
+        if (!cull) return group == 64 ? ~0ULL : (1ULL << group) - 1ULL;
+        return box_tests([&](auto &meets2) {
         // from the last pair of the group to the first, the mask shifted up by two per pair; two pairs per step, so that
         // their box reads are in flight together
         unsigned long long need = 0ULL;
@@ -797,10 +803,26 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
             need = (need << 2) | (m1 != 0ULL ? 2ULL : 0ULL) | (m0 != 0ULL ? 1ULL : 0ULL);
         }
         return need;
+        });
+    };
+    // More than four groups of 64 tiles: which of those groups does any ray meet at all?  (A group nobody meets then costs
+    // half a packed test here instead of four in the tile loop.)
+    auto groups_of_64_met = [&]() {
+        if (ONE_GROUP || !cull || p.mask_group_boxes == nullptr || p.ntiles <= 256) return ~0U;
+        return box_tests([&](auto &meets2) {
+            uint32_t met = 0U;
+            for (int k = (((p.ntiles + 63) >> 6) + 1) >> 1; k >= 1; k--) {
+                unsigned long long m1, m0;
+                meets2(p.mask_group_boxes, k - 1, m0, m1);
+                met = (met << 2) | (m1 != 0ULL ? 2U : 0U) | (m0 != 0ULL ? 1U : 0U);
+            }
+            return met;
+        });
     };
 #ifdef RT_DIAG_STAMPS
     const unsigned long long tc0 = RT_STAMP();
 #endif
+    const uint32_t met64 = groups_of_64_met();
     unsigned long long need_first = tiles_in_need(0);
 #ifdef RT_DIAG_STAMPS
     {                                                             // the box tests stay between their two stamps
@@ -1087,7 +1109,7 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
     };
     f16x8 a[2], b[2];
     for (int t0 = 0; t0 < (ONE_GROUP ? 1 : p.ntiles); t0 += 64) {
-        unsigned long long need = t0 == 0 ? need_first : tiles_in_need(t0);
+        unsigned long long need = t0 == 0 ? need_first : ((met64 >> (t0 >> 6)) & 1U) != 0U ? tiles_in_need(t0) : 0ULL;
 #ifdef RT_X_CULL_IGNORE        // marginal-cost experiment: the masks are computed and every tile is multiplied all the same
         asm volatile("" : "+s"(need));
         need |= (p.ntiles - t0 < 64) ? (1ULL << (p.ntiles - t0)) - 1ULL : ~0ULL;
