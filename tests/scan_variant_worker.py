@@ -1,7 +1,8 @@
 """Worker of test_gpu_parity.py::test_every_scan_variant_gives_the_same_image: renders a few scenes with
 every build and writes hit indices, accumulators and ray counts to an .npz file.  The test
-runs it once as is, once with RTMI_SCAN=vector (packed-FP32 scan for every scene size) and with RTMI_ORDER=caller
-(spheres kept in the caller's order on the device)."""
+runs it once as is, once with RTMI_SCAN=vector (packed-FP32 scan for every scene size), with RTMI_ORDER=caller / curve
+(other orders of the spheres on the device) and with RTMI_NO_CULL / RTMI_NO_BOX_GROUPS (the box test ahead of the matrix
+products switched off, or asked tile by tile)."""
 import os
 import sys
 
@@ -23,7 +24,7 @@ def main(out_path):
     p.vfov = 68.4
     W, H = 192, 108
     cam = rt.camera(W, H, p)
-    for n, seed in ((40, 1), (600, 2), (1300, 3), (5000, 4)):
+    for n, seed in ((40, 1), (600, 2), (1300, 3), (5000, 4), (9000, 5)):
         rt.set_world(_tie_scene(n, seed))
         for build in ("exact", "strict", "fast"):
             for rep in range(2):                       # twice: the image must not change from run to run

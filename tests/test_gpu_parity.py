@@ -447,28 +447,33 @@ def _tie_scene(n, seed):
 
 
 def test_every_scan_variant_gives_the_same_image(tmp_path):
-    """The matrix scan (image in LDS: 40 and 600 spheres; image in global memory: 1300 and 5000) and the
+    """The matrix scan (image in LDS: 40 and 600 spheres; image in global memory: 1300, 5000 and 9000) and the
     packed-FP32 scan (RTMI_SCAN=vector: geometry in LDS up to 560 spheres, in global memory beyond) are two
     filters in front of the same exact test: hit indices, accumulator bits and ray counts must be equal in
-    both builds, and equal from run to run.  The same holds for the order of the spheres on the device: the
-    library sorts them along a space-filling curve (RTMI_ORDER=caller keeps the caller's order); hits are
-    reported by the caller's index and equal distances (the scenes hold exact duplicates with different
-    materials) go to the lower caller's index either way."""
+    all builds, and equal from run to run.  The same holds for the order of the spheres on the device: the
+    library splits them in space into tiles (RTMI_ORDER=curve: along a space-filling curve only, RTMI_ORDER=caller:
+    the caller's order); hits are reported by the caller's index and equal distances (the scenes hold exact
+    duplicates with different materials) go to the lower caller's index either way.  And for the box test ahead
+    of the matrix products: a tile whose box no ray of the wave meets is not multiplied (RTMI_NO_CULL=1: every
+    tile is), scenes of more than 64 tiles ask groups of tiles first (RTMI_NO_BOX_GROUPS=1: every tile's box)."""
     import subprocess
     import sys
     from conftest import ROOT
     worker = os.path.join(ROOT, "tests", "scan_variant_worker.py")
     res = {}
-    for name, env in (("matrix", {}), ("vector", {"RTMI_SCAN": "vector"}), ("caller_order", {"RTMI_ORDER": "caller"}),
-                      ("vector_caller_order", {"RTMI_SCAN": "vector", "RTMI_ORDER": "caller"})):
+    variants = (("matrix", {}), ("vector", {"RTMI_SCAN": "vector"}), ("caller_order", {"RTMI_ORDER": "caller"}),
+                ("vector_caller_order", {"RTMI_SCAN": "vector", "RTMI_ORDER": "caller"}), ("curve_order", {"RTMI_ORDER": "curve"}),
+                ("no_cull", {"RTMI_NO_CULL": "1"}), ("no_box_groups", {"RTMI_NO_BOX_GROUPS": "1"}),
+                ("caller_order_no_box_groups", {"RTMI_ORDER": "caller", "RTMI_NO_BOX_GROUPS": "1"}))
+    for name, env in variants:
         out = str(tmp_path / (name + ".npz"))
         r = subprocess.run([sys.executable, worker, out], env=dict(os.environ, **env), cwd=ROOT,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         res[name] = np.load(out)
     keys = sorted(res["matrix"].files)
-    assert len(keys) == 4 * 3 * 2 * 3
-    for other in ("vector", "caller_order", "vector_caller_order"):
+    assert len(keys) == 5 * 3 * 2 * 3
+    for other in [name for name, _ in variants[1:]]:
         assert keys == sorted(res[other].files)
         for k in keys:
             a, b = res["matrix"][k], res[other][k]
