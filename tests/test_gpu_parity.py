@@ -486,13 +486,13 @@ def test_every_scan_variant_gives_the_same_image(tmp_path):
 
 
 @pytest.mark.parametrize("n,seed", [(1, 0), (2, 1), (7, 2), (31, 8), (32, 9), (33, 10), (65, 3), (130, 4), (257, 5),
-                                     (600, 6), (1024, 7), (1025, 11), (1100, 12), (2500, 13)])
+                                     (600, 6), (1024, 7), (1025, 11), (1100, 12), (2500, 13), (9000, 14)])
 @pytest.mark.parametrize("build,mc_rng", CHECKED)
 def test_checked_builds_match_checker_on_random_scenes(rt, n, seed, build, mc_rng):
     """Bit-exact parity away from the two shipped scenes, through every scan variant and on both sides of
     each switch: packed-FP32 scan below 32 spheres, matrix scan with its image in LDS from 32 (one tile) to
-    1024 spheres (32 tiles), matrix scan with the image read from global memory beyond: hit indices,
-    accumulators, bytes, ray counts."""
+    1024 spheres (32 tiles), matrix scan with the image read from global memory beyond (9000 spheres: more than
+    256 tiles, all three levels of the box test): hit indices, accumulators, bytes, ray counts."""
     sph = _tie_scene(n, seed)
     rt.set_world(sph)
     p = rt.default_params()
