@@ -398,11 +398,13 @@ def test_progressive_frames_equal_one_long_render(rt):
     assert np.array_equal(fast[2], rt.render(cam, W, H, 3, 20, seed=3, chunk_spp=1, build="fast")["rgba"])
 
 
-def test_scene_larger_than_the_lds_image(rt):
+@pytest.mark.parametrize("half_extent,at_least", [(25, 2048), (48, 8192)])
+def test_scene_larger_than_the_lds_image(rt, half_extent, at_least):
     """More than 2048 spheres: the per-sphere records no longer fit the LDS next to the queues and
-    are read from global memory (a separate kernel instantiation).  Same parity bars."""
-    sph = rt.scene_generate(25, 0)                      # 50x50 cells -> about 2500 spheres
-    assert len(sph) > 2048
+    are read from global memory (a separate kernel instantiation); more than 8192: over 256 tiles, the
+    box test asks groups of 64 tiles, groups of 8, then tiles.  Same parity bars."""
+    sph = rt.scene_generate(half_extent, 0)             # 50x50 cells -> about 2500 spheres, 96x96 -> about 9200
+    assert len(sph) > at_least
     rt.set_world(sph)
     W, H = 100, 56
     cam = rt.camera(W, H)
