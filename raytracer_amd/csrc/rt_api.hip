@@ -824,11 +824,12 @@ static uint32_t morton3(uint32_t x, uint32_t y, uint32_t z)
     return spread(x) | (spread(y) << 1) | (spread(z) << 2);
 }
 
-// Device order of the spheres: along the Z-order curve through their centres (cubic cells over the bulk of the
-// finite centres; equal cells keep the caller's order), so that the 32 spheres of a tile of the matrix scan
-// are neighbours in space.  The rays of a wave start near each other, and what they pass then sits in few tiles:
-// the appends, which cost per half tile that holds a candidate, fell by a quarter on the 488-sphere scene (4 % of
-// the kernel time; a shuffled list ran 6 % slower than the caller's order, which was sorted by one coordinate).
+// Device order of the spheres: the 32 spheres of a tile of the matrix scan are neighbours in space.  First along the
+// Z-order curve through their centres (cubic cells over the bulk of the finite centres; equal cells keep the caller's
+// order): the rays of a wave start near each other, and what they pass then sits in few tiles, so the appends, which
+// cost per half tile that holds a candidate, fell by a quarter on the 488-sphere scene (4 % of the kernel time; a
+// shuffled list ran 6 % slower than the caller's order, which was sorted by one coordinate).  Then (split_tiles) the
+// list is split in space so that the tiles' bounding boxes are small (below).
 // Nothing a caller sees depends on the order: hits are reported by the caller's index and equal distances go to
 // the lower caller's index (order[] travels to the device for that).
 static std::vector<int32_t> device_order(const rt_sphere *spheres, int n, bool split_tiles)

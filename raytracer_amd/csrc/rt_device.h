@@ -10,8 +10,8 @@
 
 namespace rtmi {
 
-// Device-resident world in structure-of-arrays form, in DEVICE ORDER (rt_set_world sorts the spheres along a
-// space-filling curve; orig[] maps back to the caller's indices).  One float4 per sphere and array:
+// Device-resident world in structure-of-arrays form, in DEVICE ORDER (rt_set_world splits the spheres in space into
+// tiles of 32 and sorts each tile along a space-filling curve; orig[] maps back to the caller's indices).  One float4 per sphere and array:
 //   geom[i] = { cx, cy, cz, r*r }            -- all hit_sphere (Main.c:625-653) needs to reject
 //   matA[i] = { albedo.r, albedo.g, albedo.b, fuzz }; glass, whose albedo nothing reads: { r0 entering, r0 leaving, -, - }
 //             with r0 = ((1 - ri) / (1 + ri))^2 of reflectance() (Main.c:553-554), ri = 1 / index entering, index leaving

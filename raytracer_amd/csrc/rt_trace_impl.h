@@ -691,8 +691,10 @@ __device__ __forceinline__ void queue_passes(const f32x16 &acc, const RowMaxima 
 //
 // Before a tile is multiplied the wave asks whether any of its live rays can meet the tile at all: a slab test of the ray
 // (from its origin to the nearest hit the big spheres already gave) against the axis-aligned box of the tile's spheres.
-// The spheres of a tile are neighbours in space (device order), so most tiles lie off the paths of all 64 rays: of the
-// final scene's 16 tiles a wave multiplies 7.4.  The test must never drop a sphere the exact test would accept.  That test
+// The spheres of a tile are neighbours in space (device order: the host splits the list into tiles with small boxes), so most
+// tiles lie off the paths of all 64 rays: of the final scene's 16 tiles a wave multiplies 5.1.  Two tiles are tested per
+// packed-FP32 instruction; a scene of more than 64 tiles asks the boxes of groups of tiles first (tiles_in_need).
+// The test must never drop a sphere the exact test would accept.  That test
 // accepts a sphere whose centre lies within sqrt(r^2 + E) of the ray's line, E <= 2^-21 S^2 being the rounding of its
 // discriminant per unit |d|^2 (S = |O| + max |C|): every box is widened by 2^-9 S for the ray at hand (eight times E in
 // the square), which also covers the slab arithmetic (hardware reciprocal, one FMA per plane: 2^-22 of the coordinates).
@@ -970,7 +972,7 @@ __device__ __forceinline__ void scan_spheres_matrix(const TraceParams &p, const 
 #ifndef RT_NO_OPERAND_FENCE
         asm volatile("" : "+v"(any) : "v"(x[0]), "v"(x[1]));
 #endif
-        if (__ballot(any >= 0.0f) != 0ULL) {       // two tiles in three hold no candidate at all
+        if (__ballot(any >= 0.0f) != 0ULL) {       // a tile whose box a ray meets may still hold no candidate at all
 #ifdef RT_DIAG
             const unsigned long long ta0 = RT_STAMP(), drain_before = dg.t_drain;
 #endif
