@@ -437,8 +437,15 @@ int render_common(Ctx &g, const rt_camera *cam, uint8_t *rgba, uint32_t width, u
             // costs a wave about 54 instruction times per 32-sphere tile (its matrix instructions included) plus
             // 150 for the ray features: break-even at 4 rays whatever the scene size (measured on the 488-sphere
             // scene, 1920x1080 at 1 spp per frame: 800 / 809 / 783 / 757 frames/s at 2 / 4 / 6 / 8 rays).
+            // With the box test a wave of few rays multiplies few tiles, whatever the scene holds: about 150 + 12 per
+            // tile box asked (at most the 16 of a small scene, or of the levels of a large one) + 54 for each of some three
+            // tiles, while the shared form still walks all spheres: it keeps its place in small scenes (2 rays at 488
+            // spheres; 2.64 to 2.68 ms for 1080p x 8 spp at every threshold from 0 to 4) and is off in large ones (4098
+            // spheres, 1920x1080 x 20 spp: 15.2 ms with the old threshold of 4 rays, 13.9 ms without the shared form).
             const int shared_cost = ((g.n + 63) / 64) * 26 + 60;
-            if (is_matrix(scan_variant(g))) tp.coop_max = std::max(2, std::min(16, (150 + g.ntiles * 54 + shared_cost / 2) / shared_cost));
+            if (is_matrix(scan_variant(g)) && tp.tile_boxes != nullptr)
+                tp.coop_max = std::min(16, (150 + std::min(g.ntiles, 16) * 12 + 3 * 54 + shared_cost / 2) / shared_cost);
+            else if (is_matrix(scan_variant(g))) tp.coop_max = std::max(2, std::min(16, (150 + g.ntiles * 54 + shared_cost / 2) / shared_cost));
             else tp.coop_max = std::min(16, (g.n_pad / 2 * 9 + 200) / shared_cost);
             if (const char *cm = getenv("RTMI_COOP")) tp.coop_max = std::max(0, atoi(cm));       // comparison runs
             tp.width = width; tp.height = height; tp.npix = npix;
